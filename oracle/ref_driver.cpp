@@ -1,0 +1,342 @@
+// Golden-vector generator that drives the UNMODIFIED reference classes.
+//
+// TEST INFRASTRUCTURE, not product code.  This file is ours; it is compiled
+// (oracle/Makefile, target `ref`) together with the reference sources where
+// they lie under /root/reference (cl_fft.cpp, cl_conv.cpp, cl_dconv.cpp), the
+// products go only to oracle/_ref/ (git-ignored).  It needs an OpenCL device
+// at RUN time: the authoring container has none, the MI355X box has the AMD
+// OpenCL runtime, so `oracle/_ref/ref_driver <outdir>` is run there and the
+// numeric outputs are committed under tests/golden/ref/.
+//
+// It only uses the reference's public/protected class surface:
+//   cl_fft::Clcfft / Clrfft     (cl_fft.h:29-111)
+//   cl_conv::Clpconv            (cl_conv.h:124-188)
+//   cl_conv::Cldconv            (cl_dconv.h:17-66)
+// Inputs follow the fixture PRNG of SURVEY.md §8c (LCG 1664525/1013904223).
+#include <cl_conv.h>
+#include <cl_dconv.h>
+#include <cl_fft.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+typedef std::complex<float> cf;
+
+static std::string g_dir;
+static FILE *g_manifest = nullptr;
+static bool g_first = true;
+
+static void put(const std::string &name, const void *p, size_t count,
+                const char *dtype, const std::string &shape,
+                const std::string &note) {
+  size_t esz = (!strcmp(dtype, "f64")) ? 8 : 4;
+  std::string path = g_dir + "/" + name + ".bin";
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) {
+    perror(path.c_str());
+    exit(2);
+  }
+  fwrite(p, esz, count, f);
+  fclose(f);
+  fprintf(g_manifest, "%s\n  \"%s\": {\"dtype\": \"%s\", \"shape\": [%s], \"note\": \"%s\"}",
+          g_first ? "" : ",", name.c_str(), dtype, shape.c_str(), note.c_str());
+  g_first = false;
+}
+static void put_f32(const std::string &name, const float *p, size_t n,
+                    const std::string &note) {
+  put(name, p, n, "f32", std::to_string(n), note);
+}
+static void put_c64(const std::string &name, const cf *p, size_t n,
+                    const std::string &note) {
+  put(name, p, 2 * n, "f32", std::to_string(n) + ", 2", note);
+}
+
+// fixture PRNG
+struct Lcg {
+  uint32_t s;
+  explicit Lcg(uint32_t seed) : s(seed) {}
+  uint32_t next() { return s = s * 1664525u + 1013904223u; }
+  float sym() { return (float)(next() >> 8) / 8388608.0f - 1.0f; }        // [-1,1)
+  float half() { return (float)(next() >> 8) / 16777216.0f - 0.5f; }      // [-.5,.5)
+};
+
+// decimation used for large vectors: first 64, last 64, every 16th element
+static std::vector<cf> decimate(const std::vector<cf> &v) {
+  std::vector<cf> d;
+  size_t n = v.size();
+  for (size_t i = 0; i < 64; i++) d.push_back(v[i]);
+  for (size_t i = n - 64; i < n; i++) d.push_back(v[i]);
+  for (size_t i = 0; i < n; i += 16) d.push_back(v[i]);
+  return d;
+}
+static void checks(const std::vector<cf> &v, double out[3]) {
+  double sr = 0, si = 0, e = 0;
+  for (auto &c : v) {
+    sr += c.real();
+    si += c.imag();
+    e += (double)c.real() * c.real() + (double)c.imag() * c.imag();
+  }
+  out[0] = sr;
+  out[1] = si;
+  out[2] = e;
+}
+
+// exposes the protected bit-reversal table of the reference (cl_fft.cpp:96-104)
+struct PeekCfft : cl_fft::Clcfft {
+  PeekCfft(cl_device_id d, int n) : Clcfft(d, n, true) {}
+  std::vector<int> bitrev() {
+    std::vector<int> t(N);
+    clEnqueueReadBuffer(commands, b, CL_TRUE, 0, sizeof(cl_int) * N, t.data(),
+                        0, NULL, NULL);
+    return t;
+  }
+  std::vector<cf> twiddle() {
+    std::vector<cf> t(N);
+    clEnqueueReadBuffer(commands, w, CL_TRUE, 0, sizeof(cl_float2) * N,
+                        t.data(), 0, NULL, NULL);
+    return t;
+  }
+};
+
+int main(int argc, char **argv) {
+  if (argc < 2) {
+    fprintf(stderr, "usage: ref_driver <outdir> [device-index]\n");
+    return 2;
+  }
+  g_dir = argv[1];
+  int devidx = argc > 2 ? atoi(argv[2]) : 0;
+  cl_device_id ids[32];
+  cl_uint num = 0;
+  int err = clGetDeviceIDs(NULL, CL_DEVICE_TYPE_ALL, 32, ids, &num);
+  if (err != CL_SUCCESS || num == 0) {
+    fprintf(stderr, "no OpenCL device: %s\n", cl_fft::cl_error_string(err));
+    return 3;
+  }
+  char name[128] = {0};
+  clGetDeviceInfo(ids[devidx], CL_DEVICE_NAME, 128, name, NULL);
+  fprintf(stderr, "ref_driver: %u device(s), using %d: %s\n", num, devidx, name);
+  cl_device_id dev = ids[devidx];
+
+  g_manifest = fopen((g_dir + "/manifest.json").c_str(), "w");
+  fprintf(g_manifest, "{\n  \"_device\": \"%s\"", name);
+  g_first = false;
+
+  const double PI = cl_fft::PI;
+
+  // ---- G1: test_cfft.cpp input, N=16 ------------------------------------
+  {
+    const int N = 16;
+    cl_fft::Clcfft f(dev, N, true), i(dev, N, false);
+    if (f.get_error() || i.get_error()) {
+      fprintf(stderr, "Clcfft setup error %d %d (%s)\n", f.get_error(),
+              i.get_error(), f.get_log());
+      return 4;
+    }
+    std::vector<cf> s(N);
+    for (int k = 0; k < N; k++) s[k] = cf((float)sin(k * 2 * PI / N), 0.f);
+    put_c64("g1_cfft16_in", s.data(), N, "test_cfft.cpp:54-56 input");
+    f.transform(s.data());
+    put_c64("g1_cfft16_fwd", s.data(), N, "forward (scaled 1/N)");
+    i.transform(s.data());
+    put_c64("g1_cfft16_inv", s.data(), N, "inverse of forward");
+  }
+  // ---- G2: test_rfft.cpp input, N=16 ------------------------------------
+  {
+    const int N = 16;
+    cl_fft::Clrfft f(dev, N, true), i(dev, N, false);
+    std::vector<float> sig(N);
+    std::vector<cf> spec(N / 2);
+    for (int k = 0; k < N; k++)
+      sig[k] = 0.5 + sin(k * 2 * PI / N) + 0.5 * cos(k * PI);
+    put_f32("g2_rfft16_in", sig.data(), N, "test_rfft.cpp:54-57 input");
+    f.transform(spec.data(), sig.data());
+    put_c64("g2_rfft16_fwd", spec.data(), N / 2, "packed spectrum");
+    std::vector<float> back(N);
+    i.transform(spec.data(), back.data());
+    put_f32("g2_rfft16_inv", back.data(), N, "inverse of forward");
+  }
+  // ---- G3/G4: c2c all powers of two 2..65536, LCG seed 12345 -------------
+  for (int lg = 1; lg <= 16; lg++) {
+    int N = 1 << lg;
+    cl_fft::Clcfft f(dev, N, true), i(dev, N, false);
+    Lcg r(12345);
+    std::vector<cf> x(N);
+    for (int k = 0; k < N; k++) {
+      float re = r.sym();
+      float im = r.sym();
+      x[k] = cf(re, im);
+    }
+    std::vector<cf> y = x, z = x;
+    f.transform(y.data());
+    i.transform(z.data());
+    std::vector<cf> rt = y;
+    i.transform(rt.data());
+    double c[3];
+    std::string tag = "cfft" + std::to_string(N);
+    if (N <= 4096) {
+      put_c64("g3_" + tag + "_fwd", y.data(), N, "forward of LCG(12345)");
+      put_c64("g3_" + tag + "_inv", z.data(), N, "inverse (unscaled) of LCG(12345)");
+      put_c64("g3_" + tag + "_rt", rt.data(), N, "inverse(forward(x))");
+    } else {
+      auto d = decimate(y);
+      put_c64("g4_" + tag + "_fwd_dec", d.data(), d.size(), "first64,last64,every16th");
+      d = decimate(z);
+      put_c64("g4_" + tag + "_inv_dec", d.data(), d.size(), "first64,last64,every16th");
+      d = decimate(rt);
+      put_c64("g4_" + tag + "_rt_dec", d.data(), d.size(), "first64,last64,every16th");
+    }
+    checks(y, c);
+    put("g4_" + tag + "_fwd_chk", c, 3, "f64", "3", "sum re, sum im, energy");
+    checks(z, c);
+    put("g4_" + tag + "_inv_chk", c, 3, "f64", "3", "sum re, sum im, energy");
+  }
+  // ---- G5: r2c/c2r, sizes 4..16384 (real points), LCG seed 12345 --------
+  for (int lg = 2; lg <= 17; lg++) {
+    int S = 1 << lg, M = S / 2;
+    cl_fft::Clrfft f(dev, S, true), i(dev, S, false);
+    Lcg r(12345);
+    std::vector<float> x(S);
+    for (int k = 0; k < S; k++) x[k] = r.sym();
+    std::vector<cf> spec(M);
+    f.transform(spec.data(), x.data());
+    std::vector<float> back(S);
+    std::vector<cf> tmp = spec;
+    i.transform(tmp.data(), back.data());
+    // inverse applied to an arbitrary (non-hermitian-derived) packed spectrum
+    Lcg r2(777);
+    std::vector<cf> arb(M);
+    for (int k = 0; k < M; k++) {
+      float re = r2.sym();
+      float im = r2.sym();
+      arb[k] = cf(re, im);
+    }
+    std::vector<float> arbout(S);
+    std::vector<cf> arbc = arb;
+    i.transform(arbc.data(), arbout.data());
+    std::string tag = "rfft" + std::to_string(S);
+    if (S <= 4096) {
+      put_c64("g5_" + tag + "_fwd", spec.data(), M, "packed spectrum of LCG(12345)");
+      put_f32("g5_" + tag + "_rt", back.data(), S, "inverse(forward(x))");
+      put_f32("g5_" + tag + "_invarb", arbout.data(), S, "inverse of LCG(777) packed spectrum");
+    } else {
+      auto d = decimate(spec);
+      d.push_back(spec[M / 2]);  // the self-paired bin (quirk, cl_fft.cpp:278)
+      put_c64("g5_" + tag + "_fwd_dec", d.data(), d.size(), "first64,last64,every16th,+bin M/2");
+      std::vector<cf> bc(S / 2), ac(S / 2);
+      memcpy(bc.data(), back.data(), S * 4);
+      memcpy(ac.data(), arbout.data(), S * 4);
+      d = decimate(bc);
+      put_c64("g5_" + tag + "_rt_dec", d.data(), d.size(), "real pairs; first64,last64,every16th");
+      d = decimate(ac);
+      put_c64("g5_" + tag + "_invarb_dec", d.data(), d.size(), "real pairs; first64,last64,every16th");
+    }
+    double c[3];
+    checks(spec, c);
+    put("g5_" + tag + "_fwd_chk", c, 3, "f64", "3", "sum re, sum im, energy");
+  }
+  // ---- G6: bit-reversal + twiddle tables ---------------------------------
+  for (int N : {16, 1024, 65536}) {
+    PeekCfft p(dev, N);
+    auto t = p.bitrev();
+    put("g6_bitrev" + std::to_string(N), t.data(), t.size(), "i32",
+        std::to_string(N), "cl_fft.cpp:96-104");
+    if (N <= 1024) {
+      auto w = p.twiddle();
+      put_c64("g6_twiddle" + std::to_string(N), w.data(), w.size(), "cl_fft.cpp:86-91 forward");
+    }
+  }
+  // ---- G7/G8: partitioned convolution -----------------------------------
+  auto run_pconv = [&](const std::string &tag, int pts, int nparts, int blocks,
+                       bool ones) {
+    int cvs = pts * nparts;
+    cl_conv::Clpconv c(dev, cvs, pts);
+    if (c.get_cl_err() != CL_SUCCESS) {
+      fprintf(stderr, "Clpconv setup error %d\n", c.get_cl_err());
+      exit(5);
+    }
+    Lcg r(7);
+    std::vector<float> ir(cvs), in(blocks * pts), out(blocks * pts);
+    for (auto &v : ir) v = ones ? 1.0f / cvs : r.half();
+    for (auto &v : in) v = ones ? 1.0f : r.half();
+    c.push_ir(ir.data());
+    for (int b = 0; b < blocks; b++)
+      c.convolution(&out[b * pts], &in[b * pts]);
+    put_f32(tag + "_ir", ir.data(), ir.size(), "impulse response");
+    put_f32(tag + "_in", in.data(), in.size(), "input blocks");
+    put_f32(tag + "_out", out.data(), out.size(), "Clpconv::convolution(out,in) per block");
+  };
+  run_pconv("g7_pconv_p8_n4", 8, 4, 12, false);
+  run_pconv("g7_pconv_p8_n4_ones", 8, 4, 12, true);
+  run_pconv("g7_pconv_p2_n3", 2, 3, 9, false);
+  run_pconv("g7_pconv_p64_n1", 64, 1, 4, false);
+  run_pconv("g8_pconv_p1024_n8", 1024, 8, 24, false);
+  // ---- G9: time-varying partitioned convolution --------------------------
+  {
+    int pts = 8, nparts = 4, blocks = 12, cvs = pts * nparts;
+    cl_conv::Clpconv c(dev, cvs, pts);
+    Lcg r(7);
+    std::vector<float> in1(blocks * pts), in2(blocks * pts), out(blocks * pts);
+    for (auto &v : in1) v = r.half();
+    for (auto &v : in2) v = r.half();
+    for (int b = 0; b < blocks; b++)
+      c.convolution(&out[b * pts], &in1[b * pts], &in2[b * pts]);
+    put_f32("g9_tvconv_p8_n4_in1", in1.data(), in1.size(), "input 1");
+    put_f32("g9_tvconv_p8_n4_in2", in2.data(), in2.size(), "input 2");
+    put_f32("g9_tvconv_p8_n4_out", out.data(), out.size(), "Clpconv::convolution(out,in1,in2)");
+  }
+  {
+    int pts = 256, nparts = 5, blocks = 14, cvs = pts * nparts;
+    cl_conv::Clpconv c(dev, cvs, pts);
+    Lcg r(7);
+    std::vector<float> in1(blocks * pts), in2(blocks * pts), out(blocks * pts);
+    for (auto &v : in1) v = r.half();
+    for (auto &v : in2) v = r.half();
+    for (int b = 0; b < blocks; b++)
+      c.convolution(&out[b * pts], &in1[b * pts], &in2[b * pts]);
+    put_f32("g9_tvconv_p256_n5_in1", in1.data(), in1.size(), "input 1");
+    put_f32("g9_tvconv_p256_n5_in2", in2.data(), in2.size(), "input 2");
+    put_f32("g9_tvconv_p256_n5_out", out.data(), out.size(), "Clpconv::convolution(out,in1,in2)");
+  }
+  // ---- G10: direct convolution (first non-wrapping blocks only: the
+  //           reference's wrap branch and uninitialised `del` are defects,
+  //           SURVEY.md §8a) ------------------------------------------------
+  {
+    int irsize = 16, vsize = 8, blocks = 2;
+    cl_conv::Cldconv c(dev, irsize, vsize);
+    Lcg r(7);
+    std::vector<float> ir(irsize), in(blocks * vsize), out(blocks * vsize);
+    for (auto &v : ir) v = r.half();
+    for (auto &v : in) v = r.half();
+    c.push_ir(ir.data());
+    for (int b = 0; b < blocks; b++)
+      c.convolution(&out[b * vsize], &in[b * vsize]);
+    put_f32("g10_dconv_ir", ir.data(), ir.size(), "impulse response");
+    put_f32("g10_dconv_in", in.data(), in.size(), "input");
+    put_f32("g10_dconv_out", out.data(), out.size(),
+            "Cldconv::convolution; depends on uninitialised device memory in the reference");
+  }
+  // ---- timing of the reference's own path on this device ----------------
+  {
+    const int N = 65536, reps = 20;
+    cl_fft::Clcfft f(dev, N, true);
+    std::vector<cf> x(N, cf(0.25f, -0.5f));
+    f.transform(x.data());
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; k++) f.transform(x.data());
+    auto t1 = std::chrono::steady_clock::now();
+    double us = std::chrono::duration<double, std::micro>(t1 - t0).count() / reps;
+    double v[2] = {us, N / us * 1e-3};
+    put("timing_ref_cfft65536", v, 2, "f64", "2",
+        "reference Clcfft::transform on this OpenCL device: us per transform, Gsamples/s (PCIe copies included)");
+    fprintf(stderr, "reference Clcfft N=65536: %.1f us/transform = %.4f Gsamples/s\n", us, v[1]);
+  }
+  fprintf(g_manifest, "\n}\n");
+  fclose(g_manifest);
+  fprintf(stderr, "ref_driver: done\n");
+  return 0;
+}
