@@ -1,0 +1,683 @@
+// clfft_amd.cpp — C ABI of libclfft_amd.so (see include/clfft_amd.h).
+//
+// Host side of the hot path: plan objects (the reference's Clcfft / Clrfft /
+// Clpconv / Cldconv instances), exact host tables, H2D/D2H staging for the
+// blocking host-pointer entry points, and the mapping hipError_t -> OpenCL
+// status numbers.  No CPU compute fallback exists: without a HIP device every
+// constructor reports CL_DEVICE_NOT_FOUND and every exec call fails.
+#include "../../include/clfft_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "internal.hpp"
+
+using namespace clfa;
+
+namespace {
+
+const double kPI = 3.141592653589793;  // cl_fft.h:24
+
+int map_hip(hipError_t e) {
+  switch (e) {
+    case hipSuccess: return CLFA_SUCCESS;
+    case hipErrorNoDevice: return CLFA_DEVICE_NOT_FOUND;
+    case hipErrorInvalidDevice: return CLFA_INVALID_DEVICE;
+    case hipErrorOutOfMemory: return CLFA_MEM_OBJECT_ALLOCATION_FAILURE;
+    case hipErrorInvalidValue: return CLFA_INVALID_VALUE;
+    case hipErrorInvalidDevicePointer: return CLFA_INVALID_MEM_OBJECT;
+    case hipErrorInvalidResourceHandle: return CLFA_INVALID_COMMAND_QUEUE;
+    case hipErrorNotInitialized:
+    case hipErrorInsufficientDriver: return CLFA_DEVICE_NOT_AVAILABLE;
+    default: return CLFA_OUT_OF_RESOURCES;
+  }
+}
+
+#define HIP_TRY(expr)                   \
+  do {                                  \
+    hipError_t _e = (expr);             \
+    if (_e != hipSuccess) {             \
+      (void)hipGetLastError();          \
+      return map_hip(_e);               \
+    }                                   \
+  } while (0)
+
+int ilog2(int n) {
+  int l = 0;
+  while ((1 << l) < n) l++;
+  return l;
+}
+bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// W_n^k = (cos(2 pi k/n), -sin(2 pi k/n)) rounded from double, the expression of
+// cl_fft.cpp:89-90 (`i * 2 * PI / N`) so the float values are bit-identical.
+void fill_twiddle(std::vector<cpx> &v, int count, int n, int stride, float sign) {
+  v.resize(count > 0 ? count : 1);
+  for (int i = 0; i < count; i++) {
+    int k = i * stride;
+    v[i].x = (float)cos(k * 2 * kPI / n);
+    v[i].y = sign * (float)sin(k * 2 * kPI / n);
+  }
+  if (count <= 0) v[0] = mk(1.f, 0.f);
+}
+// cl_fft.cpp:236-237 (`i * PI / N`)
+void fill_w2(std::vector<cpx> &v, int m, float sign) {
+  v.resize(m);
+  for (int i = 0; i < m; i++) {
+    v[i].x = (float)cos(i * kPI / m);
+    v[i].y = sign * (float)sin(i * kPI / m);
+  }
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t want) {
+    if (want <= bytes) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+      return map_hip(e);
+    }
+    bytes = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+int upload(DevBuf &b, const void *src, size_t bytes) {
+  int e = b.ensure(bytes);
+  if (e) return e;
+  HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int device_info(int device, DeviceInfo &di) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return CLFA_DEVICE_NOT_FOUND;
+  }
+  if (device < 0 || device >= count) return CLFA_INVALID_DEVICE;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  di.device = device;
+  di.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// plan objects
+// ---------------------------------------------------------------------------------
+
+struct clfa_fft {
+  DeviceInfo di;
+  bool real = false;     // Clrfft
+  bool fwd = true;
+  int n = 0;             // complex length (Clrfft: M = size/2, cl_fft.cpp:210)
+  int logn = 0;
+  int size = 0;          // user-visible size (n, or real points for Clrfft)
+  int err = 0;           // Clcfft::cl_err
+  int variant = 0;
+  char log[2048];
+  hipStream_t stream = nullptr;
+  DevBuf half, w2, four, scratch, stage;
+  FftTables tabs;
+};
+
+struct clfa_pconv {
+  DeviceInfo di;
+  PconvGeom g{};
+  int cvs = 0, pts = 0;
+  int wp = 0, wp2 = 0;   // cl_conv.cpp:144
+  int err = 0;
+  hipStream_t stream = nullptr;
+  DevBuf half, w2f, w2i;             // tables (cl_conv.cpp:263-287)
+  DevBuf ringA, ringB, acc, tail;    // spec1, spec2, in1-as-accumulator, olap tail
+  DevBuf in1, in2, out, ir;          // staging for the host entry points
+};
+
+struct clfa_dconv {
+  DeviceInfo di;
+  int irsize = 0, vsize = 0, wp = 0;
+  int err = 0;
+  hipStream_t stream = nullptr;
+  DevBuf del, coefs, out;
+};
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------
+// library / devices
+// ---------------------------------------------------------------------------------
+
+const char *clfa_version(void) { return "clfft_amd 0.1 (gfx950)"; }
+
+int clfa_device_count(int *count) {
+  if (!count) return CLFA_INVALID_VALUE;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess || c <= 0) {
+    (void)hipGetLastError();
+    *count = 0;
+    return CLFA_DEVICE_NOT_FOUND;
+  }
+  *count = c;
+  return CLFA_SUCCESS;
+}
+
+int clfa_device_name(int device, char *buf, size_t len) {
+  if (!buf || len == 0) return CLFA_INVALID_VALUE;
+  DeviceInfo di;
+  int e = device_info(device, di);
+  if (e) return e;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  const char *nm = prop.name[0] ? prop.name : prop.gcnArchName;
+  snprintf(buf, len, "%s", nm);
+  return CLFA_SUCCESS;
+}
+
+// message table of cl_fft::cl_error_string (cl_fft.cpp:298-395)
+const char *clfa_error_string(int err) {
+  static const struct {
+    int code;
+    const char *msg;
+  } tab[] = {{0, "Success!"}, {-1, "Device not found."}, {-2, "Device not available"},
+             {-3, "Compiler not available"}, {-4, "Memory object allocation failure"},
+             {-5, "Out of resources"}, {-6, "Out of host memory"},
+             {-7, "Profiling information not available"}, {-8, "Memory copy overlap"},
+             {-9, "Image format mismatch"}, {-10, "Image format not supported"},
+             {-11, "Program build failure"}, {-12, "Map failure"}, {-30, "Invalid value"},
+             {-31, "Invalid device type"}, {-32, "Invalid platform"}, {-33, "Invalid device"},
+             {-34, "Invalid context"}, {-35, "Invalid queue properties"}, {-36, "Invalid command queue"},
+             {-37, "Invalid host pointer"}, {-38, "Invalid memory object"},
+             {-39, "Invalid image format descriptor"}, {-40, "Invalid image size"},
+             {-41, "Invalid sampler"}, {-42, "Invalid binary"}, {-43, "Invalid build options"},
+             {-44, "Invalid program"}, {-45, "Invalid program executable"}, {-46, "Invalid kernel name"},
+             {-47, "Invalid kernel definition"}, {-48, "Invalid kernel"}, {-49, "Invalid argument index"},
+             {-50, "Invalid argument value"}, {-51, "Invalid argument size"},
+             {-52, "Invalid kernel arguments"}, {-53, "Invalid work dimension"},
+             {-54, "Invalid work group size"}, {-55, "Invalid work item size"},
+             {-56, "Invalid global offset"}, {-57, "Invalid event wait list"}, {-58, "Invalid event"},
+             {-59, "Invalid operation"}, {-60, "Invalid OpenGL object"}, {-61, "Invalid buffer size"},
+             {-62, "Invalid mip-map level"}};
+  for (const auto &t : tab)
+    if (t.code == err) return t.msg;
+  return "Unknown error";
+}
+
+// ---------------------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------------------
+
+int clfa_bitrev_table(int n, int *out) {
+  if (!out || !is_pow2(n)) return CLFA_INVALID_VALUE;
+  // doubling construction of cl_fft.cpp:96-101
+  out[0] = 0;
+  for (int i = 1, h = n / 2; i < n; i <<= 1, h >>= 1)
+    for (int j = 0; j < i; j++) out[i + j] = out[j] + h;
+  return CLFA_SUCCESS;
+}
+
+int clfa_twiddle_table(int n, int forward, float *out) {
+  if (!out || n < 1) return CLFA_INVALID_VALUE;
+  std::vector<cpx> v;
+  fill_twiddle(v, n, n, 1, forward ? -1.f : 1.f);
+  memcpy(out, v.data(), sizeof(cpx) * n);
+  return CLFA_SUCCESS;
+}
+
+int clfa_r2c_twiddle_table(int m, int forward, float *out) {
+  if (!out || m < 1) return CLFA_INVALID_VALUE;
+  std::vector<cpx> v;
+  fill_w2(v, m, forward ? -1.f : 1.f);
+  memcpy(out, v.data(), sizeof(cpx) * m);
+  return CLFA_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------
+// FFT plans
+// ---------------------------------------------------------------------------------
+
+static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool fwd) {
+  p->real = real;
+  p->fwd = fwd;
+  p->n = n;
+  p->size = size;
+  p->log[0] = 0;
+  if (!is_pow2(n) || n < 2 || n > (1 << kMaxLog)) {
+    snprintf(p->log, sizeof(p->log), "size must be a power of two, complex length 2..65536 (got %d)", n);
+    return CLFA_INVALID_VALUE;
+  }
+  p->logn = ilog2(n);
+  int e = device_info(device, p->di);
+  if (e) return e;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  std::vector<cpx> h;
+  if (p->logn <= kLdsMaxLog) {
+    fill_twiddle(h, n / 2, n, 1, -1.f);
+    if ((e = upload(p->half, h.data(), sizeof(cpx) * h.size()))) return e;
+    p->tabs.half = (const cpx *)p->half.p;
+  } else {
+    int l1, l2, llo;
+    fourstep_split(p->logn, &l1, &l2, &llo);
+    int n1 = 1 << l1, n2 = 1 << l2, lo = 1 << llo, hi = n >> llo;
+    std::vector<cpx> all, part;
+    fill_twiddle(part, n1 / 2, n1, 1, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + n1 / 2);
+    fill_twiddle(part, n2 / 2, n2, 1, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + n2 / 2);
+    fill_twiddle(part, lo, n, 1, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + lo);
+    fill_twiddle(part, hi, n, lo, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + hi);
+    if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
+    p->tabs.four = (const cpx *)p->four.p;
+    size_t sbytes = (size_t)fourstep_grid(p->logn, p->variant, p->di) * n * sizeof(cpx);
+    if ((e = p->scratch.ensure(sbytes))) return e;
+  }
+  if (real) {
+    fill_w2(h, n, fwd ? -1.f : 1.f);
+    if ((e = upload(p->w2, h.data(), sizeof(cpx) * n))) return e;
+    p->tabs.w2 = (const cpx *)p->w2.p;
+  }
+  return CLFA_SUCCESS;
+}
+
+int clfa_cfft_create(clfa_fft **plan, int device, int n, int forward) {
+  if (!plan) return CLFA_INVALID_VALUE;
+  clfa_fft *p = new (std::nothrow) clfa_fft();
+  if (!p) return CLFA_OUT_OF_HOST_MEMORY;
+  p->err = fft_setup(p, device, n, false, n, forward != 0);
+  *plan = p;
+  return p->err;
+}
+
+int clfa_rfft_create(clfa_fft **plan, int device, int size, int forward) {
+  if (!plan) return CLFA_INVALID_VALUE;
+  clfa_fft *p = new (std::nothrow) clfa_fft();
+  if (!p) return CLFA_OUT_OF_HOST_MEMORY;
+  if (size < 4 || !is_pow2(size)) {
+    p->log[0] = 0;
+    snprintf(p->log, sizeof(p->log), "real size must be a power of two, 4..131072 (got %d)", size);
+    p->err = CLFA_INVALID_VALUE;
+  } else {
+    p->err = fft_setup(p, device, size / 2, true, size, forward != 0);
+  }
+  *plan = p;
+  return p->err;
+}
+
+void clfa_fft_destroy(clfa_fft *p) {
+  if (!p) return;
+  if (p->stream) {
+    (void)hipSetDevice(p->di.device);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipStreamDestroy(p->stream);
+  }
+  p->half.release();
+  p->w2.release();
+  p->four.release();
+  p->scratch.release();
+  p->stage.release();
+  delete p;
+}
+
+int clfa_fft_get_error(const clfa_fft *p) { return p ? p->err : CLFA_INVALID_VALUE; }
+const char *clfa_fft_get_log(const clfa_fft *p) { return p ? p->log : ""; }
+size_t clfa_fft_workspace_bytes(const clfa_fft *p) { return p ? p->scratch.bytes : 0; }
+
+const char *clfa_fft_kernel_name(const clfa_fft *p) {
+  if (!p) return "";
+  return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn, p->fwd, p->variant);
+}
+
+int clfa_fft_set_variant(clfa_fft *p, int variant) {
+  if (!p || variant < 0 || variant > 6) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  p->variant = variant;
+  if (p->logn > kLdsMaxLog) {
+    HIP_TRY(hipSetDevice(p->di.device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    size_t sbytes = (size_t)fourstep_grid(p->logn, variant, p->di) * p->n * sizeof(cpx);
+    int e = p->scratch.ensure(sbytes);
+    if (e) return e;
+  }
+  return CLFA_SUCCESS;
+}
+
+int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!data || batch < 0) return CLFA_INVALID_VALUE;
+  if (batch == 0) return CLFA_SUCCESS;
+  HIP_TRY(hipSetDevice(p->di.device));
+  hipStream_t s = (hipStream_t)stream;  // NULL is the HIP default stream
+  cpx *d = (cpx *)data;
+  const bool scale = p->fwd;  // cl_fft.cpp:39-40: forward plans divide by N, inverse plans do not
+  if (p->logn <= kLdsMaxLog) {
+    int mode = !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R);
+    HIP_TRY(launch_fft_lds(p->logn, p->fwd, mode, scale, d, p->tabs, batch, p->di, s));
+    return CLFA_SUCCESS;
+  }
+  if (p->real && !p->fwd) HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, p->n, batch, s));
+  HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, p->variant, d, (cpx *)p->scratch.p, p->tabs, batch, p->di, s));
+  if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, p->n, batch, s));
+  return CLFA_SUCCESS;
+}
+
+// host staging in chunks of at most ~256 MiB so huge host batches do not need a
+// device buffer of their full size
+static long chunk_batches(size_t bytes_per_batch, long batch) {
+  size_t cap = (size_t)256 << 20;
+  long c = (long)(cap / bytes_per_batch);
+  if (c < 1) c = 1;
+  return c < batch ? c : batch;
+}
+
+int clfa_cfft_transform(clfa_fft *p, float *c, long batch) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!c || batch < 0 || p->real) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(p->di.device));
+  const size_t per = sizeof(cpx) * (size_t)p->n;
+  const long cb = chunk_batches(per, batch);
+  for (long b0 = 0; b0 < batch; b0 += cb) {
+    long nb = batch - b0 < cb ? batch - b0 : cb;
+    int e = p->stage.ensure(per * nb);
+    if (e) return e;
+    char *h = (char *)c + per * b0;
+    HIP_TRY(hipMemcpyAsync(p->stage.p, h, per * nb, hipMemcpyHostToDevice, p->stream));   // cl_fft.cpp:155
+    if ((e = clfa_fft_exec_dev(p, p->stage.p, nb, p->stream))) return e;                   // cl_fft.cpp:157
+    HIP_TRY(hipMemcpyAsync(h, p->stage.p, per * nb, hipMemcpyDeviceToHost, p->stream));   // cl_fft.cpp:158
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  return CLFA_SUCCESS;
+}
+
+int clfa_rfft_transform(clfa_fft *p, float *c, float *r, long batch) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!c || !r || batch < 0 || !p->real) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(p->di.device));
+  const size_t per = sizeof(cpx) * (size_t)p->n;  // size floats == M complex
+  const long cb = chunk_batches(per, batch);
+  // forward reads r and writes c; inverse reads c and writes r (cl_fft.cpp:272-294)
+  char *src = (char *)(p->fwd ? (void *)r : (void *)c);
+  char *dst = (char *)(p->fwd ? (void *)c : (void *)r);
+  for (long b0 = 0; b0 < batch; b0 += cb) {
+    long nb = batch - b0 < cb ? batch - b0 : cb;
+    int e = p->stage.ensure(per * nb);
+    if (e) return e;
+    HIP_TRY(hipMemcpyAsync(p->stage.p, src + per * b0, per * nb, hipMemcpyHostToDevice, p->stream));
+    if ((e = clfa_fft_exec_dev(p, p->stage.p, nb, p->stream))) return e;
+    HIP_TRY(hipMemcpyAsync(dst + per * b0, p->stage.p, per * nb, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  return CLFA_SUCCESS;
+}
+
+int clfa_reorder_dev(int device, void *out, const void *in, int n, long batch, void *stream) {
+  if (!out || !in || out == in || !is_pow2(n) || n < 2 || batch < 0) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_reorder((cpx *)out, (const cpx *)in, ilog2(n), batch, (hipStream_t)stream));
+  return CLFA_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------
+// partitioned convolution
+// ---------------------------------------------------------------------------------
+
+static int pconv_setup(clfa_pconv *p, int device, int cvs, int pts, int channels) {
+  p->cvs = cvs;
+  p->pts = pts;
+  if (!is_pow2(pts) || pts < 2 || pts > (1 << kPconvMaxLogBins) || cvs < pts || channels < 1)
+    return CLFA_INVALID_VALUE;
+  p->g.bins = pts;                 // cl_conv.cpp:143
+  p->g.logb = ilog2(pts);
+  p->g.nparts = cvs / pts;         // floor: remainder samples are dropped
+  p->g.channels = channels;
+  p->wp = 0;
+  p->wp2 = p->g.nparts - 1;        // cl_conv.cpp:144
+  int e = device_info(device, p->di);
+  if (e) return e;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  std::vector<cpx> h;
+  fill_twiddle(h, pts / 2, pts, 1, -1.f);
+  if ((e = upload(p->half, h.data(), sizeof(cpx) * h.size()))) return e;
+  fill_w2(h, pts, -1.f);           // cl_conv.cpp:276-281
+  if ((e = upload(p->w2f, h.data(), sizeof(cpx) * pts))) return e;
+  fill_w2(h, pts, 1.f);            // cl_conv.cpp:282-287
+  if ((e = upload(p->w2i, h.data(), sizeof(cpx) * pts))) return e;
+  const size_t ring = sizeof(cpx) * (size_t)channels * p->g.nparts * pts;
+  const size_t blk = sizeof(float) * (size_t)channels * pts;
+  if ((e = p->ringA.ensure(ring))) return e;
+  if ((e = p->ringB.ensure(ring))) return e;
+  if ((e = p->acc.ensure(sizeof(cpx) * (size_t)channels * pts))) return e;
+  if ((e = p->tail.ensure(blk))) return e;
+  // zero-initialised state (cl_conv.cpp:303-313)
+  HIP_TRY(hipMemsetAsync(p->ringA.p, 0, ring, p->stream));
+  HIP_TRY(hipMemsetAsync(p->ringB.p, 0, ring, p->stream));
+  HIP_TRY(hipMemsetAsync(p->tail.p, 0, blk, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return CLFA_SUCCESS;
+}
+
+int clfa_pconv_create(clfa_pconv **pc, int device, int cvs, int pts, int channels) {
+  if (!pc) return CLFA_INVALID_VALUE;
+  clfa_pconv *p = new (std::nothrow) clfa_pconv();
+  if (!p) return CLFA_OUT_OF_HOST_MEMORY;
+  p->err = pconv_setup(p, device, cvs, pts, channels);
+  *pc = p;
+  return p->err;
+}
+
+void clfa_pconv_destroy(clfa_pconv *p) {
+  if (!p) return;
+  if (p->stream) {
+    (void)hipSetDevice(p->di.device);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipStreamDestroy(p->stream);
+  }
+  for (DevBuf *b : {&p->half, &p->w2f, &p->w2i, &p->ringA, &p->ringB, &p->acc, &p->tail, &p->in1, &p->in2,
+                    &p->out, &p->ir})
+    b->release();
+  delete p;
+}
+
+int clfa_pconv_get_error(const clfa_pconv *p) { return p ? p->err : CLFA_INVALID_VALUE; }
+int clfa_pconv_nparts(const clfa_pconv *p) { return p ? p->g.nparts : 0; }
+int clfa_pconv_wp(const clfa_pconv *p) { return p ? p->wp : -1; }
+int clfa_pconv_wp2(const clfa_pconv *p) { return p ? p->wp2 : -1; }
+size_t clfa_pconv_state_bytes(const clfa_pconv *p) {
+  return p ? p->ringA.bytes + p->ringB.bytes + p->acc.bytes + p->tail.bytes : 0;
+}
+
+int clfa_pconv_push_ir_dev(clfa_pconv *p, const void *ir, void *stream) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!ir) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(p->di.device));
+  hipStream_t s = (hipStream_t)stream;
+  const long stride = (long)p->g.nparts * p->pts;
+  // cl_conv.cpp:358-386: partition i -> frame wp2, wp2 counts down from nparts-1
+  for (int i = 0; i < p->g.nparts; i++) {
+    HIP_TRY(launch_pconv_forward(p->g, (const float *)ir + (long)i * p->pts, stride, (cpx *)p->ringB.p, p->wp2,
+                                 (const cpx *)p->half.p, (const cpx *)p->w2f.p, s));
+    p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;
+  }
+  return CLFA_SUCCESS;
+}
+
+int clfa_pconv_push_ir(clfa_pconv *p, const float *ir) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!ir) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(p->di.device));
+  const size_t bytes = sizeof(float) * (size_t)p->g.channels * p->g.nparts * p->pts;
+  int e = p->ir.ensure(bytes);
+  if (e) return e;
+  HIP_TRY(hipMemcpyAsync(p->ir.p, ir, bytes, hipMemcpyHostToDevice, p->stream));
+  if ((e = clfa_pconv_push_ir_dev(p, p->ir.p, p->stream))) return e;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return CLFA_SUCCESS;
+}
+
+int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void *in2, void *stream) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!out || !in1) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(p->di.device));
+  hipStream_t s = (hipStream_t)stream;
+  const cpx *half = (const cpx *)p->half.p;
+  // forward chain(s): cl_conv.cpp:399-419 / 465-513
+  HIP_TRY(launch_pconv_forward(p->g, (const float *)in1, p->pts, (cpx *)p->ringA.p, p->wp, half,
+                               (const cpx *)p->w2f.p, s));
+  if (in2)
+    HIP_TRY(launch_pconv_forward(p->g, (const float *)in2, p->pts, (cpx *)p->ringB.p, p->wp2, half,
+                                 (const cpx *)p->w2f.p, s));
+  p->wp = p->wp != p->g.nparts - 1 ? p->wp + 1 : 0;            // cl_conv.cpp:424 / 516
+  if (in2) p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;  // cl_conv.cpp:519
+  // cl_conv.cpp:428-449
+  HIP_TRY(launch_pconv_mac(p->g, (const cpx *)p->ringA.p, (const cpx *)p->ringB.p, p->wp, (cpx *)p->acc.p, s));
+  HIP_TRY(launch_pconv_inverse(p->g, (const cpx *)p->acc.p, (float *)p->tail.p, (float *)out, half,
+                               (const cpx *)p->w2i.p, s));
+  return CLFA_SUCCESS;
+}
+
+static int pconv_host(clfa_pconv *p, float *out, const float *in1, const float *in2) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!out || !in1) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(p->di.device));
+  const size_t blk = sizeof(float) * (size_t)p->g.channels * p->pts;
+  int e;
+  if ((e = p->in1.ensure(blk)) || (e = p->out.ensure(blk))) return e;
+  HIP_TRY(hipMemcpyAsync(p->in1.p, in1, blk, hipMemcpyHostToDevice, p->stream));
+  if (in2) {
+    if ((e = p->in2.ensure(blk))) return e;
+    HIP_TRY(hipMemcpyAsync(p->in2.p, in2, blk, hipMemcpyHostToDevice, p->stream));
+  }
+  if ((e = clfa_pconv_process_dev(p, p->out.p, p->in1.p, in2 ? p->in2.p : nullptr, p->stream))) return e;
+  HIP_TRY(hipMemcpyAsync(out, p->out.p, blk, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));   // blocking read, cl_conv.cpp:455
+  return CLFA_SUCCESS;
+}
+
+int clfa_pconv_convolution(clfa_pconv *p, float *out, const float *in) { return pconv_host(p, out, in, nullptr); }
+int clfa_pconv_convolution_tv(clfa_pconv *p, float *out, const float *in1, const float *in2) {
+  if (!in2) return CLFA_INVALID_VALUE;
+  return pconv_host(p, out, in1, in2);
+}
+
+// ---------------------------------------------------------------------------------
+// direct convolution
+// ---------------------------------------------------------------------------------
+
+int clfa_dconv_create(clfa_dconv **dc, int device, int irsize, int vsize) {
+  if (!dc) return CLFA_INVALID_VALUE;
+  clfa_dconv *d = new (std::nothrow) clfa_dconv();
+  if (!d) return CLFA_OUT_OF_HOST_MEMORY;
+  *dc = d;
+  d->irsize = irsize;
+  d->vsize = vsize;
+  auto setup = [&]() -> int {
+    if (irsize < 1 || vsize < 1 || (long)irsize * vsize > 0x7fffffffL) return CLFA_INVALID_VALUE;
+    int e = device_info(device, d->di);
+    if (e) return e;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    const size_t ring = sizeof(float) * ((size_t)irsize + vsize);
+    if ((e = d->del.ensure(ring)) || (e = d->coefs.ensure(ring)) || (e = d->out.ensure(sizeof(float) * vsize)))
+      return e;
+    // the reference leaves these uninitialised (cl_dconv.cpp:87-91); zero is the intent
+    HIP_TRY(hipMemsetAsync(d->del.p, 0, ring, d->stream));
+    HIP_TRY(hipMemsetAsync(d->coefs.p, 0, ring, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return CLFA_SUCCESS;
+  };
+  d->err = setup();
+  return d->err;
+}
+
+void clfa_dconv_destroy(clfa_dconv *d) {
+  if (!d) return;
+  if (d->stream) {
+    (void)hipSetDevice(d->di.device);
+    (void)hipStreamSynchronize(d->stream);
+    (void)hipStreamDestroy(d->stream);
+  }
+  d->del.release();
+  d->coefs.release();
+  d->out.release();
+  delete d;
+}
+
+int clfa_dconv_get_error(const clfa_dconv *d) { return d ? d->err : CLFA_INVALID_VALUE; }
+
+int clfa_dconv_push_ir(clfa_dconv *d, const float *ir) {
+  if (!d) return CLFA_INVALID_VALUE;
+  if (d->err) return d->err;
+  if (!ir) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(d->di.device));
+  HIP_TRY(hipMemcpyAsync(d->coefs.p, ir, sizeof(float) * d->irsize, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return CLFA_SUCCESS;
+}
+
+// ring write of vsize floats at wp with wrap-around (intent of cl_dconv.cpp:112-122)
+static int ring_write(clfa_dconv *d, DevBuf &ring, const float *src) {
+  const int end = d->irsize + d->vsize;
+  int first = end - d->wp < d->vsize ? end - d->wp : d->vsize;
+  HIP_TRY(hipMemcpyAsync((float *)ring.p + d->wp, src, sizeof(float) * first, hipMemcpyHostToDevice, d->stream));
+  if (first < d->vsize)
+    HIP_TRY(hipMemcpyAsync(ring.p, src + first, sizeof(float) * (d->vsize - first), hipMemcpyHostToDevice,
+                           d->stream));
+  return CLFA_SUCCESS;
+}
+
+int clfa_dconv_convolution(clfa_dconv *d, float *out, const float *in) {
+  if (!d) return CLFA_INVALID_VALUE;
+  if (d->err) return d->err;
+  if (!out || !in) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(d->di.device));
+  int e = ring_write(d, d->del, in);
+  if (e) return e;
+  d->wp = (d->wp + d->vsize) % (d->irsize + d->vsize);   // cl_dconv.cpp:124
+  HIP_TRY(launch_dconv((float *)d->out.p, (const float *)d->del.p, (const float *)d->coefs.p, d->irsize,
+                       d->vsize, d->wp, d->stream));
+  HIP_TRY(hipMemcpyAsync(out, d->out.p, sizeof(float) * d->vsize, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return CLFA_SUCCESS;
+}
+
+int clfa_dconv_convolution_tv(clfa_dconv *d, float *out, const float *in1, const float *in2) {
+  if (!d) return CLFA_INVALID_VALUE;
+  if (d->err) return d->err;
+  if (!out || !in1 || !in2) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(d->di.device));
+  int e = ring_write(d, d->coefs, in2);   // cl_dconv.cpp:134-147
+  if (e) return e;
+  return clfa_dconv_convolution(d, out, in1);
+}
+
+}  // extern "C"

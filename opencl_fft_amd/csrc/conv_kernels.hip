@@ -1,0 +1,281 @@
+// conv_kernels.hip — uniformly partitioned overlap-add convolution and direct
+// convolution for gfx950 (MI355X), batched over independent channels.
+//
+// The reference runs 26 launches per block and channel (cl_conv.cpp:393-458:
+// reorder, 10 x fft, r2c, convol with float CAS atomics, c2r, reorder, 10 x fft,
+// olap).  Here a block is three launches for ALL channels:
+//   k_pconv_fwd  real block -> zero-padded real FFT -> packed frame in the ring
+//                (reorder + fft + r2c fused; the transform lives in VGPRs + LDS)
+//   k_pconv_mac  acc[n] = sum_p A[(wp+p) % nparts][n] (.) B[p][n]; one lane owns
+//                two bins and walks the partitions in registers: no atomics,
+//                deterministic order, 16-byte coalesced streaming of both rings
+//   k_pconv_inv  c2r + inverse FFT + overlap-add + 1/bins scaling fused
+// The rings are channels x nparts x bins complex64, resident in HBM.
+#include "fft_wg.hpp"
+
+namespace clfa {
+
+// ---------------------------------------------------------------------------------
+// forward: in (channels x pts floats) -> ring frame
+// ---------------------------------------------------------------------------------
+template <int LOGB>
+__global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_fwd(const float *__restrict__ in, long in_stride,
+                                                                cpx *__restrict__ ring, int frame, int nparts,
+                                                                int channels, const cpx *__restrict__ tab_g,
+                                                                const cpx *__restrict__ w2_g) {
+  using G = LdsGeom<LOGB>;
+  constexpr int N = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
+  __shared__ cpx s_tab[G::HALF];
+  __shared__ cpx s_x[FPW * G::PADN];
+  const int tid = threadIdx.x;
+  const int f = tid / T, t = tid % T;
+  for (int i = tid; i < N / 2; i += WG) s_tab[i] = tab_g[i];
+  __syncthreads();
+  cpx *xb = s_x + f * G::PADN;
+  const int groups = (channels + FPW - 1) / FPW;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int ch = g * FPW + f;
+    const bool active = ch < channels;
+    // the real block reinterpreted as N/2 complex values, upper half zero
+    // (cl_conv.cpp:399: only bytes>>1 of in1 are written; the rest is zero)
+    const cpx *src = reinterpret_cast<const cpx *>(in + (long)(active ? ch : 0) * in_stride);
+    cpx v[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int p = t + T * e;
+      v[e] = (active && p < N / 2) ? src[p] : mk(0.f, 0.f);
+    }
+    wg_passes<LOGB, G::LOGE, 0, true>(v, t, s_tab, xb);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; e++) xb[lds_pad(t + T * e)] = v[e];
+    __syncthreads();
+    if (active) {
+      cpx *x = ring + ((long)ch * nparts + frame) * N;
+      for (int i = t; i < N / 2; i += T) {
+        if (i == 0) {
+          cpx z = xb[0];
+          x[0] = mk((z.x + z.y) * .5f, (z.x - z.y) * .5f);
+          x[N / 2] = xb[lds_pad(N / 2)];
+        } else {
+          cpx oi, oj;
+          r2c_pair(xb[lds_pad(i)], xb[lds_pad(N - i)], w2_g[i], oi, oj);
+          x[i] = oi;
+          x[N - i] = oj;
+        }
+      }
+    }
+  }
+}
+
+template <int LOGB>
+static hipError_t launch_fwd_one(const PconvGeom &g, const float *in, long in_stride, cpx *ring, int frame,
+                                 const cpx *half, const cpx *w2f, hipStream_t s) {
+  using G = LdsGeom<LOGB>;
+  int groups = (g.channels + G::FPW - 1) / G::FPW;
+  int grid = groups < 4096 ? groups : 4096;
+  hipLaunchKernelGGL((k_pconv_fwd<LOGB>), dim3(grid), dim3(G::WG), 0, s, in, in_stride, ring, frame, g.nparts,
+                     g.channels, half, w2f);
+  return hipGetLastError();
+}
+
+hipError_t launch_pconv_forward(const PconvGeom &g, const float *in, long in_stride, cpx *ring, int frame,
+                                const cpx *half, const cpx *w2f, hipStream_t s) {
+  switch (g.logb) {
+#define CLFA_B(L) \
+  case L:         \
+    return launch_fwd_one<L>(g, in, in_stride, ring, frame, half, w2f, s);
+    CLFA_B(1) CLFA_B(2) CLFA_B(3) CLFA_B(4) CLFA_B(5) CLFA_B(6) CLFA_B(7) CLFA_B(8) CLFA_B(9) CLFA_B(10)
+    CLFA_B(11) CLFA_B(12) CLFA_B(13)
+#undef CLFA_B
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// multiply-accumulate over partitions (reference convol, cl_conv_kernels.h:102-118)
+// ---------------------------------------------------------------------------------
+struct alignas(16) cpx2 {
+  cpx a, b;
+};
+
+// one lane = two adjacent bins (16 B) of one channel; loops the partitions
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, const cpx *__restrict__ B,
+                                                   cpx *__restrict__ acc, int wp, int bins, int nparts,
+                                                   long total /* channels * bins/2 */) {
+  const int hb = bins >> 1;
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long ch = g / hb;
+    const int i2 = (int)(g % hb);
+    const cpx2 *a = reinterpret_cast<const cpx2 *>(A + ch * (long)nparts * bins) + i2;
+    const cpx2 *b = reinterpret_cast<const cpx2 *>(B + ch * (long)nparts * bins) + i2;
+    cpx s0 = mk(0.f, 0.f), s1 = mk(0.f, 0.f);
+    int fr = wp;  // ring frame of partition p = 0 (the oldest input block)
+    int p = 0;
+    for (; p + UNROLL <= nparts; p += UNROLL) {
+      cpx2 av[UNROLL], bv[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+        int f = fr + u;
+        f = f < nparts ? f : f - nparts;
+        av[u] = a[(long)f * hb];
+        bv[u] = b[(long)(p + u) * hb];
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+        if (i2 == 0) {  // packed DC / Nyquist bin: (re*re, im*im)
+          s0.x += av[u].a.x * bv[u].a.x;
+          s0.y += av[u].a.y * bv[u].a.y;
+        } else {
+          s0 = cadd(s0, cmul(av[u].a, bv[u].a));
+        }
+        s1 = cadd(s1, cmul(av[u].b, bv[u].b));
+      }
+      fr += UNROLL;
+      fr = fr < nparts ? fr : fr - nparts;
+    }
+    for (; p < nparts; p++) {
+      cpx2 av = a[(long)fr * hb], bv = b[(long)p * hb];
+      if (i2 == 0) {
+        s0.x += av.a.x * bv.a.x;
+        s0.y += av.a.y * bv.a.y;
+      } else {
+        s0 = cadd(s0, cmul(av.a, bv.a));
+      }
+      s1 = cadd(s1, cmul(av.b, bv.b));
+      fr = fr + 1 < nparts ? fr + 1 : 0;
+    }
+    cpx2 o;
+    o.a = s0;
+    o.b = s1;
+    reinterpret_cast<cpx2 *>(acc + ch * (long)bins)[i2] = o;
+  }
+}
+
+hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp, cpx *acc,
+                            hipStream_t s) {
+  long total = (long)g.channels * (g.bins / 2);
+  long grid = (total + 255) / 256;
+  if (grid > 256 * 64) grid = 256 * 64;
+  hipLaunchKernelGGL((k_pconv_mac<4>), dim3((int)grid), dim3(256), 0, s, ringA, ringB, acc, wp, g.bins,
+                     g.nparts, total);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// inverse: acc -> c2r -> inverse FFT -> overlap-add (reference c2r + reorder +
+// fft + olap, cl_conv_kernels.h:87-100, 120-124)
+// ---------------------------------------------------------------------------------
+template <int LOGB>
+__global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_inv(const cpx *__restrict__ acc,
+                                                                float *__restrict__ tail,
+                                                                float *__restrict__ out, int channels,
+                                                                const cpx *__restrict__ tab_g,
+                                                                const cpx *__restrict__ w2_g) {
+  using G = LdsGeom<LOGB>;
+  constexpr int N = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
+  __shared__ cpx s_tab[G::HALF];
+  __shared__ cpx s_x[FPW * G::PADN];
+  const int tid = threadIdx.x;
+  const int f = tid / T, t = tid % T;
+  for (int i = tid; i < N / 2; i += WG) s_tab[i] = tab_g[i];
+  __syncthreads();
+  cpx *xb = s_x + f * G::PADN;
+  const int groups = (channels + FPW - 1) / FPW;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int ch = g * FPW + f;
+    const bool active = ch < channels;
+    const cpx *x = acc + (long)(active ? ch : 0) * N;
+    __syncthreads();
+    if (active) {
+      for (int i = t; i < N / 2; i += T) {
+        if (i == 0) {
+          cpx c0 = x[0];
+          xb[0] = mk(c0.x + c0.y, c0.x - c0.y);
+          xb[lds_pad(N / 2)] = x[N / 2];
+        } else {
+          cpx oi, oj;
+          c2r_pair(x[i], x[N - i], w2_g[i], oi, oj);
+          xb[lds_pad(i)] = oi;
+          xb[lds_pad(N - i)] = oj;
+        }
+      }
+    }
+    __syncthreads();
+    cpx v[E];
+    pass_gather<LOGB, G::LOGE>(v, t, [&](int p) { return xb[lds_pad(p)]; });
+    wg_passes<LOGB, G::LOGE, 0, false>(v, t, s_tab, xb);
+    if (active) {
+      // v[e] holds real samples 2p, 2p+1 of the 2*bins-point block, p = t + T*e.
+      // p < N/2: output half (+ old tail, / bins); p >= N/2: the new tail, unscaled.
+      constexpr float inv = 1.0f / (float)N;
+      cpx *o = reinterpret_cast<cpx *>(out + (long)ch * N);
+      cpx *tl = reinterpret_cast<cpx *>(tail + (long)ch * N);
+      if constexpr (E >= 2) {
+#pragma unroll
+        for (int e = 0; e < E / 2; e++) {
+          const int p = t + T * e;
+          cpx old = tl[p];
+          o[p] = mk((v[e].x + old.x) * inv, (v[e].y + old.y) * inv);
+          tl[p] = v[e + E / 2];
+        }
+      }
+    }
+  }
+}
+
+template <int LOGB>
+static hipError_t launch_inv_one(const PconvGeom &g, const cpx *acc, float *tail, float *out, const cpx *half,
+                                 const cpx *w2i, hipStream_t s) {
+  using G = LdsGeom<LOGB>;
+  int groups = (g.channels + G::FPW - 1) / G::FPW;
+  int grid = groups < 4096 ? groups : 4096;
+  hipLaunchKernelGGL((k_pconv_inv<LOGB>), dim3(grid), dim3(G::WG), 0, s, acc, tail, out, g.channels, half, w2i);
+  return hipGetLastError();
+}
+
+hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail, float *out, const cpx *half,
+                                const cpx *w2i, hipStream_t s) {
+  switch (g.logb) {
+#define CLFA_B(L) \
+  case L:         \
+    return launch_inv_one<L>(g, acc, tail, out, half, w2i, s);
+    CLFA_B(1) CLFA_B(2) CLFA_B(3) CLFA_B(4) CLFA_B(5) CLFA_B(6) CLFA_B(7) CLFA_B(8) CLFA_B(9) CLFA_B(10)
+    CLFA_B(11) CLFA_B(12) CLFA_B(13)
+#undef CLFA_B
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// direct convolution (reference convol, cl_dconv.cpp:32-43): one workgroup per
+// output sample, lanes stride the taps, tree reduction instead of CAS atomics
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dconv(float *__restrict__ out, const float *__restrict__ del,
+                                               const float *__restrict__ coefs, int irsize, int vsize, int rp) {
+  __shared__ float s_part[4];
+  const int n = blockIdx.x;
+  const int end = irsize + vsize;
+  float acc = 0.f;
+  for (int h = threadIdx.x; h < irsize; h += 256) {
+    int r = rp + n + h;
+    r = r < end ? r : r % end;
+    acc += del[r] * coefs[irsize - 1 - h];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[n] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+hipError_t launch_dconv(float *out, const float *del, const float *coefs, int irsize, int vsize, int rp,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_dconv, dim3(vsize), dim3(256), 0, s, out, del, coefs, irsize, vsize, rp);
+  return hipGetLastError();
+}
+
+}  // namespace clfa

@@ -1,0 +1,75 @@
+// internal.hpp — launcher prototypes shared by the kernel files and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fft_device.hpp"
+
+namespace clfa {
+
+enum FftMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2 };
+
+// Largest complex length the single-workgroup LDS kernel handles; above it
+// the four-step kernel (two phases through an on-die scratch) takes over.
+constexpr int kLdsMaxLog = 13;
+constexpr int kMaxLog = 16;  // reference int32 index bound, cl_fft.cpp:32
+
+struct FftTables {      // all device pointers, owned by the plan
+  const cpx *half = nullptr;   // W_n^k, k < n/2, forward sign (LDS path; n = complex length)
+  const cpx *w2 = nullptr;     // r2c table (cl_fft.cpp:233-238), sign of the plan's direction, m entries
+  const cpx *four = nullptr;   // four-step tables: [half N1 | half N2 | lo | hi]
+};
+
+struct DeviceInfo {
+  int device = 0;
+  int num_cus = 256;
+};
+
+// single-workgroup LDS FFT, n = 2^logn <= 2^kLdsMaxLog.  mode selects the fused
+// r2c epilogue / c2r prologue.  scale: multiply by 1/n (forward plans).
+hipError_t launch_fft_lds(int logn, bool fwd, int mode, bool scale, cpx *data, const FftTables &t,
+                          long batch, const DeviceInfo &di, hipStream_t s);
+const char *name_fft_lds(int logn, bool fwd, int mode);
+
+// four-step FFT, n = 2^logn in (2^kLdsMaxLog, 2^kMaxLog]; scratch = grid * n complex
+int fourstep_grid(int logn, int variant, const DeviceInfo &di);
+hipError_t launch_fft_4step(int logn, bool fwd, bool scale, int variant, cpx *data, cpx *scratch,
+                            const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
+const char *name_fft_4step(int logn, bool fwd, int variant);
+int fourstep_split(int logn, int *logn1, int *logn2, int *loglo);
+
+// stand-alone pack / unpack (reference kernels conv / iconv) for M above the LDS path
+hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
+hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
+
+// reference `reorder` kernel as an op
+hipError_t launch_reorder(cpx *out, const cpx *in, int logn, long batch, hipStream_t s);
+
+// ---- partitioned convolution --------------------------------------------------
+struct PconvGeom {
+  int logb;      // log2(bins), bins = pts
+  int bins;
+  int nparts;
+  int channels;
+};
+// input block (channels x pts floats) -> zero-padded 2*pts real FFT -> packed
+// spectrum frame `frame` of ring (channels x nparts x bins complex).  Unscaled,
+// reference pack (cl_conv_kernels.h:46-85).
+hipError_t launch_pconv_forward(const PconvGeom &g, const float *in, long in_stride, cpx *ring, int frame,
+                                const cpx *half, const cpx *w2f, hipStream_t s);
+// acc = sum_p A[(wp+p)%nparts] (.) B[p]  (cl_conv_kernels.h:102-118), acc: channels x bins complex
+hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp, cpx *acc,
+                            hipStream_t s);
+// acc -> c2r -> inverse FFT -> overlap-add (cl_conv_kernels.h:87-100,120-124); out channels x pts,
+// tail channels x pts (unscaled second half kept for the next block)
+hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail, float *out,
+                                const cpx *half, const cpx *w2i, hipStream_t s);
+// fused: MAC + inverse in one kernel (one workgroup per channel)
+hipError_t launch_pconv_mac_inverse(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp,
+                                    float *tail, float *out, const cpx *half, const cpx *w2i, hipStream_t s);
+constexpr int kPconvMaxLogBins = 13;
+
+// ---- direct convolution ----------------------------------------------------------
+hipError_t launch_dconv(float *out, const float *del, const float *coefs, int irsize, int vsize, int rp,
+                        hipStream_t s);
+
+}  // namespace clfa

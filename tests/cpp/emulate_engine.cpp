@@ -1,0 +1,88 @@
+// CPU emulation of the lane-level FFT engine (opencl_fft_amd/csrc/fft_device.hpp):
+// runs the very same pass_compute / pass_scatter / pass_gather code lane by lane,
+// with a std::vector standing in for LDS, and checks it against a float64 DFT.
+// Built and run by tests/test_engine_emulation.py (no GPU needed).
+#include "../../opencl_fft_amd/csrc/fft_device.hpp"
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <vector>
+
+using namespace clfa;
+
+template <int LOGN, int LOGE, int LOGNS, bool FWD>
+static void run(std::vector<cpx> &regs, const std::vector<cpx> &tab, std::vector<cpx> &lds) {
+  constexpr int E = 1 << LOGE, T = 1 << (LOGN - LOGE);
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
+  for (int tid = 0; tid < T; tid++)
+    pass_compute<LOGN, LOGE, LOGNS, FWD>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, tab);
+  if constexpr (LOGNS + LOGR < LOGN) {
+    for (int tid = 0; tid < T; tid++)
+      pass_scatter<LOGN, LOGE, LOGNS>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid,
+                                      [&](int p, cpx v) { lds[lds_pad(p)] = v; });
+    for (int tid = 0; tid < T; tid++)
+      pass_gather<LOGN, LOGE>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid,
+                              [&](int p) { return lds[lds_pad(p)]; });
+    run<LOGN, LOGE, LOGNS + LOGR, FWD>(regs, tab, lds);
+  }
+}
+
+template <int LOGN, int LOGE, bool FWD> static double check() {
+  constexpr int n = 1 << LOGN, E = 1 << LOGE, T = n / E;
+  std::vector<cpx> x(n), tab(n / 2 > 0 ? n / 2 : 1), regs(n), lds(lds_padded_size(n));
+  unsigned s = 12345u + LOGN;
+  for (auto &c : x) {
+    s = s * 1664525u + 1013904223u; c.x = (float)(s >> 8) / 8388608.0f - 1.0f;
+    s = s * 1664525u + 1013904223u; c.y = (float)(s >> 8) / 8388608.0f - 1.0f;
+  }
+  const double PI = 3.141592653589793;
+  for (int i = 0; i < n / 2; i++) tab[i] = mk((float)cos(i * 2 * PI / n), -(float)sin(i * 2 * PI / n));
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) regs[tid * E + e] = x[tid + T * e];
+  run<LOGN, LOGE, 0, FWD>(regs, tab, lds);
+  // float64 DFT (O(n^2) for small n, else recursive radix-2)
+  std::vector<std::complex<double>> ref(n);
+  {
+    std::vector<std::complex<double>> a(n);
+    for (int i = 0; i < n; i++) a[i] = {x[i].x, x[i].y};
+    // iterative radix-2 in double
+    for (int i = 0, j = 0; i < n; i++) {
+      if (i < j) std::swap(a[i], a[j]);
+      int m = n >> 1;
+      while (m >= 1 && (j & m)) { j ^= m; m >>= 1; }
+      j |= m;
+    }
+    for (int len = 2; len <= n; len <<= 1)
+      for (int i = 0; i < n; i += len)
+        for (int k = 0; k < len / 2; k++) {
+          double ang = (FWD ? -2 : 2) * PI * k / len;
+          std::complex<double> w(cos(ang), sin(ang)), u = a[i + k], t = w * a[i + k + len / 2];
+          a[i + k] = u + t; a[i + k + len / 2] = u - t;
+        }
+    ref = a;
+  }
+  double num = 0, den = 0;
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) {
+      std::complex<double> y(regs[tid * E + e].x, regs[tid * E + e].y);
+      num += std::norm(y - ref[tid + T * e]);
+      den += std::norm(ref[tid + T * e]);
+    }
+  return sqrt(num / den);
+}
+
+static int g_fail = 0;
+template <int LOGN, int LOGE> static void both() {
+  double a = check<LOGN, LOGE, true>(), b = check<LOGN, LOGE, false>();
+  printf("n=2^%-2d E=%-2d relL2 fwd %.3g inv %.3g\n", LOGN, 1 << LOGE, a, b);
+  if (!(a < 5e-7) || !(b < 5e-7)) g_fail = 1;
+}
+
+int main() {
+  both<1, 1>(); both<2, 2>(); both<3, 3>(); both<4, 4>(); both<5, 4>(); both<6, 4>(); both<7, 4>();
+  both<8, 4>(); both<9, 4>(); both<10, 4>(); both<11, 4>(); both<12, 4>(); both<13, 4>(); both<14, 4>();
+  both<6, 2>(); both<6, 3>(); both<10, 3>(); both<9, 2>(); both<7, 3>(); both<8, 3>();
+  puts(g_fail ? "FAIL" : "OK");
+  return g_fail;
+}

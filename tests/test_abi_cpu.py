@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: libclfft_amd.so loads, exports every
+symbol include/clfft_amd.h declares, and its host-only entry points (tables,
+error strings) match the oracle bit for bit.  No compute calls: there is no GPU
+here, and the library has no CPU fallback (constructors must say so)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import opencl_fft_amd as fa
+from opencl_fft_amd import _lib
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "clfft_amd.h")).read()
+    return sorted(set(re.findall(r"CLFA_API[^;(]*?\b(clfa_\w+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    names = _declared()
+    assert len(names) >= 35
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "libclfft_amd.so does not export %s" % n
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert bound == set(names), (bound ^ set(names))
+
+
+def test_no_oracle_or_cpu_fallback_linked():
+    """the product library must not contain the oracle"""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    assert "orc_" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "opencl_fft_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), "%s mentions the oracle" % f
+
+
+@pytest.mark.parametrize("n", [2, 16, 1024, 65536])
+def test_tables_match_oracle_bit_exact(n):
+    assert np.array_equal(fa.bitrev_table(n), oracle.bitrev_table(n))
+    for fwd in (True, False):
+        assert np.array_equal(fa.twiddle_table(n, fwd).view(np.uint32), oracle.twiddle_table(n, fwd).view(np.uint32))
+        assert np.array_equal(fa.r2c_twiddle_table(n, fwd).view(np.uint32),
+                              oracle.r2c_twiddle_table(n, fwd).view(np.uint32))
+
+
+def test_error_strings_follow_cl_numbering():
+    # cl_fft.cpp:298-395
+    assert fa.cl_error_string(0) == "Success!"
+    assert fa.cl_error_string(-1) == "Device not found."
+    assert fa.cl_error_string(-5) == "Out of resources"
+    assert fa.cl_error_string(-30) == "Invalid value"
+    assert fa.cl_error_string(-54) == "Invalid work group size"
+    assert fa.cl_error_string(-62) == "Invalid mip-map level"
+    assert fa.cl_error_string(12345) == "Unknown error"
+
+
+def test_fails_loudly_without_a_device():
+    if fa.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    plan = fa.Clcfft(0, 1024, True)
+    assert plan.get_error() == -1 and fa.cl_error_string(plan.get_error()) == "Device not found."
+    x = np.ones(1024, np.complex64)
+    assert plan.transform(x) == -1
+    assert np.all(x == 1)                       # untouched: nothing computed on the CPU
+    assert fa.Clrfft(0, 1024, True).get_error() == -1
+    msgs = []
+    pc = fa.Clpconv(0, 4096, 1024, errs=lambda s, d: msgs.append(s))
+    assert pc.get_cl_err() == -1 and msgs == ["Device not found."]
+    assert fa.Cldconv(0, 64, 8, uData=object()).get_cl_err() == -1
+
+
+def test_engine_emulation_on_cpu(tmp_path):
+    """the lane-level pass code of fft_device.hpp, run lane by lane on the host"""
+    exe = str(tmp_path / "emulate_engine")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "emulate_engine.cpp"),
+                           "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert out.strip().endswith("OK"), out

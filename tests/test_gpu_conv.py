@@ -1,0 +1,180 @@
+"""GPU parity tests for partitioned and direct convolution (through the C ABI)
+against the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+
+import opencl_fft_amd as fa
+from oracle import oracle
+from tests import util
+from tests.util import assert_parity, golden
+
+pytestmark = pytest.mark.gpu
+
+# The reference sums partitions with float CAS atomics in arbitrary order
+# (cl_conv_kernels.h:116-117); ours sums in ascending partition order in
+# registers.  Same tolerance as the spectra, applied to the time-domain output.
+CTOL = 2e-6
+
+
+def _run(p, blocks, pts, in1, in2=None):
+    outs = []
+    for b in range(blocks):
+        o = np.zeros((p.channels, pts), np.float32)
+        a = in1[..., b * pts:(b + 1) * pts]
+        if in2 is None:
+            assert p.convolution(o, a) == 0
+        else:
+            assert p.convolution(o, a, in2[..., b * pts:(b + 1) * pts]) == 0
+        outs.append(o)
+    return np.concatenate(outs, axis=-1)
+
+
+@pytest.mark.parametrize("tag,pts,nparts,blocks", [
+    ("g7_pconv_p8_n4", 8, 4, 12), ("g7_pconv_p8_n4_ones", 8, 4, 12),
+    ("g7_pconv_p2_n3", 2, 3, 9), ("g7_pconv_p64_n1", 64, 1, 4),
+    ("g8_pconv_p1024_n8", 1024, 8, 24)])
+def test_pconv_vs_reference(tag, pts, nparts, blocks):
+    ir, inp = golden(tag + "_ir"), golden(tag + "_in")
+    p = fa.Clpconv(0, pts * nparts, pts)
+    assert p.get_cl_err() == 0 and p.nparts == nparts
+    assert p.push_ir(ir) == 0
+    out = _run(p, blocks, pts, inp[None, :])[0]
+    assert_parity(out, golden(tag + "_out"), tol=CTOL, what=tag)
+
+
+def test_pconv_ring_indices_bit_exact():
+    p, o = fa.Clpconv(0, 32, 8), oracle.Pconv(32, 8)
+    assert (p.nparts, p.wp, p.wp2) == (o.nparts, o.wp, o.wp2) == (4, 0, 3)
+    z = np.zeros(32, np.float32)
+    p.push_ir(z)
+    o.push_ir(z)
+    assert p.wp2 == o.wp2 == 3
+    out = np.zeros((1, 8), np.float32)
+    for _ in range(9):
+        p.convolution(out, z[:8])
+        o.convolution(z[:8])
+        assert (p.wp, p.wp2) == (o.wp, o.wp2)
+    q, oq = fa.Clpconv(0, 32, 8), oracle.Pconv(32, 8)
+    for _ in range(7):
+        q.convolution(out, z[:8], z[:8])
+        oq.convolution(z[:8], z[:8])
+        assert (q.wp, q.wp2) == (oq.wp, oq.wp2)
+
+
+@pytest.mark.parametrize("pts,nparts,channels,blocks", [(2, 1, 3, 4), (16, 5, 7, 12), (256, 3, 5, 8), (1024, 6, 3, 9),
+                                                        (4096, 2, 2, 5), (8192, 2, 1, 4)])
+def test_pconv_multichannel_vs_oracle(pts, nparts, channels, blocks):
+    """`channels` independent instances in one object == that many oracle objects"""
+    s = util.lcg_half(7 + pts, channels * (pts * nparts + pts * blocks))
+    ir = s[:channels * pts * nparts].reshape(channels, pts * nparts)
+    x = s[channels * pts * nparts:].reshape(channels, pts * blocks)
+    p = fa.Clpconv(0, pts * nparts, pts, channels=channels)
+    assert p.get_cl_err() == 0
+    assert p.push_ir(ir) == 0
+    out = _run(p, blocks, pts, x)
+    for c in range(channels):
+        o = oracle.Pconv(pts * nparts, pts)
+        o.push_ir(ir[c])
+        want = np.concatenate([o.convolution(x[c, b * pts:(b + 1) * pts]) for b in range(blocks)])
+        assert_parity(out[c], want, tol=CTOL, what="channel %d" % c)
+
+
+def test_pconv_nparts_floor_and_bad_geometry():
+    assert fa.Clpconv(0, 96000, 1024).nparts == 93        # remainder dropped, cl_conv.cpp:143
+    msgs = []
+    bad = fa.Clpconv(0, 100, 24, errs=lambda s, d: msgs.append((s, d)), uData="u")
+    assert bad.get_cl_err() == -30 and msgs == [("Invalid value", "u")]
+    assert bad.convolution(np.zeros((1, 24), np.float32), np.zeros(24, np.float32)) == -30
+
+
+@pytest.mark.parametrize("tag,pts,nparts,blocks", [("g9_tvconv_p8_n4", 8, 4, 12), ("g9_tvconv_p256_n5", 256, 5, 14)])
+def test_tvconv_vs_reference(tag, pts, nparts, blocks):
+    in1, in2 = golden(tag + "_in1"), golden(tag + "_in2")
+    p = fa.Clpconv(0, pts * nparts, pts)
+    out = _run(p, blocks, pts, in1[None, :], in2[None, :])[0]
+    assert_parity(out, golden(tag + "_out"), tol=CTOL, what=tag)
+
+
+def test_tvconv_multichannel_vs_oracle():
+    pts, nparts, channels, blocks = 64, 4, 3, 11
+    s = util.lcg_half(9, 2 * channels * pts * blocks)
+    x1 = s[:channels * pts * blocks].reshape(channels, -1)
+    x2 = s[channels * pts * blocks:].reshape(channels, -1)
+    p = fa.Clpconv(0, pts * nparts, pts, channels=channels)
+    out = _run(p, blocks, pts, x1, x2)
+    for c in range(channels):
+        o = oracle.Pconv(pts * nparts, pts)
+        want = np.concatenate([o.convolution(x1[c, b * pts:(b + 1) * pts], x2[c, b * pts:(b + 1) * pts])
+                               for b in range(blocks)])
+        assert_parity(out[c], want, tol=CTOL, what="channel %d" % c)
+
+
+def test_pconv_device_resident_config4_shape():
+    """config 4 geometry at reduced channel count: pts=1024, cvs=96256 (94 partitions)"""
+    import torch
+    pts, nparts, channels, blocks = 1024, 94, 4, 6
+    s = util.lcg_half(11, channels * (pts * nparts + pts * blocks))
+    ir = (s[:channels * pts * nparts] / np.float32(np.sqrt(pts * nparts))).reshape(channels, -1)
+    x = (2 * s[channels * pts * nparts:]).reshape(channels, -1)
+    p = fa.Clpconv(0, 96256, pts, channels=channels)
+    assert p.nparts == nparts
+    d_ir = torch.from_numpy(ir).cuda()
+    assert p.push_ir_device(d_ir) == 0
+    d_x = torch.from_numpy(x).cuda()
+    outs = []
+    for b in range(blocks):
+        d_in = d_x[:, b * pts:(b + 1) * pts].contiguous()
+        d_out = torch.empty((channels, pts), device="cuda")
+        assert p.process_device(d_out, d_in) == 0
+        outs.append(d_out)
+    torch.cuda.synchronize()
+    out = torch.cat(outs, dim=1).cpu().numpy()
+    for c in range(channels):
+        o = oracle.Pconv(96256, pts)
+        o.push_ir(ir[c])
+        want = np.concatenate([o.convolution(x[c, b * pts:(b + 1) * pts]) for b in range(blocks)])
+        assert_parity(out[c], want, tol=CTOL, what="channel %d" % c)
+
+
+# ---- direct convolution ----------------------------------------------------------------------
+
+def test_dconv_vs_reference_and_oracle():
+    ir, inp = golden("g10_dconv_ir"), golden("g10_dconv_in")
+    d, o = fa.Cldconv(0, 16, 8), oracle.Dconv(16, 8)
+    assert d.get_cl_err() == 0
+    assert d.push_ir(ir) == 0
+    o.push_ir(ir)
+    outs, wants = [], []
+    for b in range(2):
+        out = np.zeros(8, np.float32)
+        assert d.convolution(out, inp[b * 8:(b + 1) * 8]) == 0
+        outs.append(out)
+        wants.append(o.convolution(inp[b * 8:(b + 1) * 8]))
+    assert_parity(np.concatenate(outs), np.concatenate(wants), tol=CTOL, what="vs oracle")
+    assert_parity(np.concatenate(outs), golden("g10_dconv_out"), tol=CTOL, what="vs reference")
+
+
+@pytest.mark.parametrize("irsize,vsize,blocks", [(16, 8, 9), (1000, 64, 40), (5, 7, 6), (4096, 32, 10)])
+def test_dconv_ring_wrap_vs_oracle(irsize, vsize, blocks):
+    s = util.lcg_half(3, irsize + vsize * blocks)
+    ir, x = s[:irsize], s[irsize:]
+    d, o = fa.Cldconv(0, irsize, vsize), oracle.Dconv(irsize, vsize)
+    d.push_ir(ir)
+    o.push_ir(ir)
+    for b in range(blocks):
+        out = np.zeros(vsize, np.float32)
+        assert d.convolution(out, x[b * vsize:(b + 1) * vsize]) == 0
+        assert_parity(out, o.convolution(x[b * vsize:(b + 1) * vsize]), tol=5e-6, what="block %d" % b)
+
+
+def test_dconv_time_varying_vs_oracle():
+    irsize, vsize, blocks = 32, 8, 12
+    s = util.lcg_half(5, 2 * vsize * blocks)
+    x1, x2 = s[:vsize * blocks], s[vsize * blocks:]
+    d, o = fa.Cldconv(0, irsize, vsize), oracle.Dconv(irsize, vsize)
+    for b in range(blocks):
+        out = np.zeros(vsize, np.float32)
+        sl = slice(b * vsize, (b + 1) * vsize)
+        assert d.convolution(out, x1[sl], x2[sl]) == 0
+        want = o.convolution(x1[sl], x2[sl])
+        assert np.max(np.abs(out - want)) <= 5e-6 * max(1e-3, np.max(np.abs(want)))

@@ -1,0 +1,248 @@
+"""GPU parity tests for the FFT path: HIP kernels (through the C ABI of
+libclfft_amd.so) against the CPU oracle and the reference's golden vectors.
+
+Bar: integer/index work bit-exact; float32 spectra within
+TOL = 1e-6 in both ||y-ref||2/||ref||2 and max|y-ref|/max|ref|.
+"""
+import numpy as np
+import pytest
+
+import opencl_fft_amd as fa
+from oracle import oracle
+from tests import util
+from tests.util import TOL, assert_parity, golden
+
+pytestmark = pytest.mark.gpu
+
+CSIZES = [1 << k for k in range(1, 17)]
+RSIZES = [1 << k for k in range(2, 18)]
+
+
+def _c2c(n, fwd, x):
+    plan = fa.Clcfft(0, n, fwd)
+    assert plan.get_error() == 0, plan.get_log()
+    y = np.array(x, dtype=np.complex64, copy=True)
+    assert plan.transform(y) == 0
+    return y
+
+
+def test_device_visible():
+    assert fa.device_count() >= 1
+    assert fa.device_name(0)
+
+
+# ---- tables (host side of the ABI, bit-exact) ---------------------------------
+
+@pytest.mark.parametrize("n", [16, 1024, 65536])
+def test_tables_bit_exact(n):
+    assert np.array_equal(fa.bitrev_table(n), oracle.bitrev_table(n))
+    assert np.array_equal(fa.bitrev_table(n), golden("g6_bitrev%d" % n))
+    for fwd in (True, False):
+        assert np.array_equal(fa.twiddle_table(n, fwd).view(np.uint32), oracle.twiddle_table(n, fwd).view(np.uint32))
+        assert np.array_equal(fa.r2c_twiddle_table(n, fwd).view(np.uint32),
+                              oracle.r2c_twiddle_table(n, fwd).view(np.uint32))
+
+
+# ---- a4: reorder kernel, bit-exact ------------------------------------------------
+
+@pytest.mark.parametrize("n,batch", [(2, 3), (16, 5), (1024, 7), (65536, 3)])
+def test_reorder_bit_exact(n, batch):
+    import torch
+    x = util.lcg_complex(99, n * batch).reshape(batch, n)
+    d_in = torch.from_numpy(x.view(np.float32).copy()).cuda()
+    d_out = torch.zeros_like(d_in)
+    assert fa.reorder_device(0, d_out, d_in, n, batch) == 0
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.complex64).reshape(batch, n)
+    b = oracle.bitrev_table(n)
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(x[:, b]).view(np.uint32))
+
+
+# ---- a5/a6: c2c -------------------------------------------------------------------------
+
+def test_kat_test_cfft_n16():
+    x = golden("g1_cfft16_in")
+    y = _c2c(16, True, x)
+    want = np.zeros(16, np.complex64)
+    want[1], want[15] = -0.5j, 0.5j
+    assert np.max(np.abs(y - want)) < 1e-7
+    assert_parity(_c2c(16, False, y), golden("g1_cfft16_inv"), what="inv")
+
+
+@pytest.mark.parametrize("n", CSIZES)
+def test_cfft_vs_oracle_and_reference(n):
+    x = util.lcg_complex(12345, n)
+    for fwd in (True, False):
+        y = _c2c(n, fwd, x)
+        assert_parity(y, oracle.cfft(x, fwd), what="n=%d fwd=%s vs oracle" % (n, fwd))
+        tag = "fwd" if fwd else "inv"
+        if n <= 4096:
+            assert_parity(y, golden("g3_cfft%d_%s" % (n, tag)), what="vs reference")
+        else:
+            assert_parity(util.decimate(y), golden("g4_cfft%d_%s_dec" % (n, tag)), what="vs reference")
+
+
+@pytest.mark.parametrize("n,batch", [(2, 1000), (8, 333), (64, 37), (256, 17), (1024, 9), (4096, 5), (8192, 3),
+                                     (16384, 3), (32768, 2), (65536, 3)])
+def test_cfft_batched_ragged(n, batch):
+    """batch counts that do not divide the transforms-per-workgroup packing"""
+    x = util.lcg_complex(4242 + n, n * batch).reshape(batch, n)
+    for fwd in (True, False):
+        y = _c2c(n, fwd, x)
+        assert_parity(y, oracle.cfft(x, fwd), what="n=%d batch=%d" % (n, batch))
+
+
+def test_cfft_empty_batch_and_bad_sizes():
+    plan = fa.Clcfft(0, 64, True)
+    assert plan.transform(np.zeros((0, 64), np.complex64)) == 0
+    assert plan.transform(np.zeros(32, np.complex64)) == -30
+    for n in (0, 1, 3, 1000, 131072):
+        bad = fa.Clcfft(0, n, True)
+        assert bad.get_error() == -30 and fa.cl_error_string(bad.get_error()) == "Invalid value"
+        assert bad.transform(np.zeros(max(n, 1), np.complex64)) == -30
+    assert fa.Clcfft(99, 64, True).get_error() == -33
+
+
+def test_cfft_roundtrip_and_linearity_65536():
+    n = 65536
+    x = util.lcg_complex(1, n)
+    z = util.lcg_complex(2, n)
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    X, Z, S = x.copy(), z.copy(), (x + 2 * z).astype(np.complex64)
+    assert f.transform(X) == 0 and f.transform(Z) == 0 and f.transform(S) == 0
+    assert_parity(S, X + 2 * Z, tol=2e-6, what="linearity")
+    back = X.copy()
+    assert i.transform(back) == 0
+    assert_parity(back, x, what="inverse(forward(x)) == x")
+
+
+def test_cfft_device_resident_batch():
+    """device-pointer entry point on a torch buffer, checked on a few batches + Parseval on all"""
+    import torch
+    n, batch = 65536, 96
+    g = torch.Generator(device="cuda").manual_seed(7)
+    d = torch.rand((batch, n, 2), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    x = d.cpu().numpy().view(np.complex64).reshape(batch, n)
+    plan = fa.Clcfft(0, n, True)
+    assert plan.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    y = d.cpu().numpy().view(np.complex64).reshape(batch, n)
+    for b in (0, 1, batch // 2, batch - 1):
+        assert_parity(y[b], oracle.cfft(x[b], True), what="batch %d" % b)
+    e_in = np.sum(np.abs(x.astype(np.complex128)) ** 2, axis=1)
+    e_out = np.sum(np.abs(y.astype(np.complex128)) ** 2, axis=1) * n
+    assert np.max(np.abs(e_out / e_in - 1)) < 1e-5
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+def test_cfft_large_kernel_variants(variant):
+    n, batch = 65536, 5
+    x = util.lcg_complex(31 + variant, n * batch).reshape(batch, n)
+    plan = fa.Clcfft(0, n, True)
+    assert plan.set_variant(variant) == 0
+    y = x.copy()
+    assert plan.transform(y) == 0
+    assert_parity(y, oracle.cfft(x, True), what="variant %d" % variant)
+
+
+# ---- a7/a8/a9: r2c / c2r -----------------------------------------------------------------
+
+def test_kat_test_rfft_n16():
+    x = golden("g2_rfft16_in").copy()
+    spec = np.zeros(8, np.complex64)
+    assert fa.Clrfft(0, 16, True).transform(spec, x) == 0
+    want = np.zeros(8, np.complex64)
+    want[0], want[1] = 0.5 + 0.5j, -1.0j
+    assert np.max(np.abs(spec - want)) < 2e-7
+    back = np.zeros(16, np.float32)
+    assert fa.Clrfft(0, 16, False).transform(spec, back) == 0
+    assert_parity(back, golden("g2_rfft16_inv"), what="inv")
+
+
+@pytest.mark.parametrize("size", RSIZES)
+def test_rfft_vs_oracle_and_reference(size):
+    m = size // 2
+    x = util.lcg_sym(12345, size)
+    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+    assert f.get_error() == 0 and i.get_error() == 0
+    spec = np.zeros(m, np.complex64)
+    assert f.transform(spec, x.copy()) == 0
+    ospec = oracle.rfft_forward(x)
+    assert_parity(spec, ospec, what="fwd vs oracle")
+    # the self-paired bin keeps the reference's quirk (never conjugated, cl_fft.cpp:278)
+    assert abs(spec[m // 2] - ospec[m // 2]) <= TOL * np.max(np.abs(ospec))
+    back = np.zeros(size, np.float32)
+    assert i.transform(spec.copy(), back) == 0
+    assert_parity(back, oracle.rfft_inverse(ospec), what="inv vs oracle")
+    arb = util.lcg_complex(777, m)
+    arbout = np.zeros(size, np.float32)
+    assert i.transform(arb.copy(), arbout) == 0
+    if size <= 4096:
+        assert_parity(spec, golden("g5_rfft%d_fwd" % size), what="fwd vs reference")
+        assert_parity(back, golden("g5_rfft%d_rt" % size), what="rt vs reference")
+        assert_parity(arbout, golden("g5_rfft%d_invarb" % size), what="invarb vs reference")
+    else:
+        got = np.concatenate([util.decimate(spec), spec[m // 2:m // 2 + 1]])
+        assert_parity(got, golden("g5_rfft%d_fwd_dec" % size), what="fwd vs reference")
+        assert_parity(util.decimate(back.view(np.complex64)), golden("g5_rfft%d_rt_dec" % size), what="rt")
+        assert_parity(util.decimate(arbout.view(np.complex64)), golden("g5_rfft%d_invarb_dec" % size), what="invarb")
+
+
+@pytest.mark.parametrize("size,batch", [(4, 777), (64, 130), (2048, 9), (16384, 11), (65536, 3)])
+def test_rfft_batched_in_place(size, batch):
+    x = util.lcg_sym(55 + size, size * batch).reshape(batch, size)
+    buf = x.copy().view(np.complex64)
+    assert fa.Clrfft(0, size, True).transform(buf) == 0      # in-place form, cl_fft.h:104-109
+    assert_parity(buf, oracle.rfft_forward(x), what="fwd in place")
+    assert fa.Clrfft(0, size, False).transform(buf) == 0
+    assert_parity(buf.view(np.float32), x, what="round trip")
+
+
+def test_rfft_bad_sizes():
+    for s in (0, 2, 3, 12, 262144):
+        assert fa.Clrfft(0, s, True).get_error() == -30
+
+
+# ---- full BASELINE sizes: size-independent properties -------------------------------------
+
+def test_config2_full_size_roundtrip_parseval():
+    """config 2 of BASELINE.json: 4096 x 65536 c2c in HBM; inverse(forward(x)) == x,
+    Parseval on every batch, four batches against the oracle"""
+    import torch
+    n, batch = 65536, 4096
+    g = torch.Generator(device="cuda").manual_seed(2024)
+    d = torch.rand((batch, n, 2), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    keep = {b: d[b].cpu().numpy().view(np.complex64).reshape(n) for b in (0, 1, 2047, 4095)}
+    e_in = (d.double() ** 2).sum(dim=(1, 2))
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    assert f.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    e_out = (d.double() ** 2).sum(dim=(1, 2)) * n
+    assert float(((e_out / e_in) - 1).abs().max()) < 1e-5
+    for b, x in keep.items():
+        assert_parity(d[b].cpu().numpy().view(np.complex64).reshape(n), oracle.cfft(x, True), what="batch %d" % b)
+    assert i.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    for b, x in keep.items():
+        assert_parity(d[b].cpu().numpy().view(np.complex64).reshape(n), x, what="round trip batch %d" % b)
+    e_rt = (d.double() ** 2).sum(dim=(1, 2))
+    assert float(((e_rt / e_in) - 1).abs().max()) < 1e-5
+
+
+def test_config3_full_size_roundtrip():
+    """config 3: r2c + c2r, 16384 real x 8192 batches, packed in place"""
+    import torch
+    size, batch = 16384, 8192
+    g = torch.Generator(device="cuda").manual_seed(3)
+    d = torch.rand((batch, size), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    orig = d.clone()
+    keep = {b: d[b].cpu().numpy() for b in (0, 4095, 8191)}
+    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+    assert f.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    for b, x in keep.items():
+        assert_parity(d[b].cpu().numpy().view(np.complex64), oracle.rfft_forward(x), what="fwd batch %d" % b)
+    assert i.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    err = float((d - orig).double().norm() / orig.double().norm())
+    assert err < TOL

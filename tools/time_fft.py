@@ -1,0 +1,43 @@
+"""dev tool: time the large-N kernel variants with HIP events (run on the GPU box)."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+import opencl_fft_amd as fa
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+def main():
+    n, batch = 65536, 4096
+    d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
+    src = d.clone()
+    ms = timeit(lambda: d.copy_(src))
+    print("copy 2GiB->2GiB: %.3f ms = %.2f TB/s (r+w)" % (ms, 2 * d.numel() * 4 / ms / 1e9))
+    for variant in [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6]:
+        plan = fa.Clcfft(0, n, True)
+        assert plan.set_variant(variant) == 0
+        d.copy_(src)
+        ms = timeit(lambda: plan.exec_device(d, batch))
+        gs = batch * n / ms / 1e6
+        print("variant %d: %.3f ms  %.1f Gsamples/s  alg %.2f TB/s" % (variant, ms, gs, gs * 16 / 1e3), flush=True)
+    for size, batch in [(16384, 8192)]:
+        x = torch.rand((batch, size), device="cuda") * 2 - 1
+        f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+        ms = timeit(lambda: f.exec_device(x, batch))
+        print("r2c %d x %d: %.3f ms alg %.2f TB/s" % (size, batch, ms, batch * size * 8 / ms / 1e9))
+        ms = timeit(lambda: i.exec_device(x, batch))
+        print("c2r %d x %d: %.3f ms alg %.2f TB/s" % (size, batch, ms, batch * size * 8 / ms / 1e9))
+    for n, batch in [(1024, 262144), (4096, 65536), (8192, 32768), (256, 1 << 20)]:
+        x = torch.rand((batch, n, 2), device="cuda") * 2 - 1
+        f = fa.Clcfft(0, n, True)
+        ms = timeit(lambda: f.exec_device(x, batch))
+        print("c2c %d x %d: %.3f ms alg %.2f TB/s" % (n, batch, ms, batch * n * 16 / ms / 1e9))
+
+main()
