@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of BASELINE.json: batched 1-D c2c FFT, N=65536,
+float32, 4096 batches per GPU, device-resident, in place.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (one batched transform) over the rank's 4096 x 65536
+complex samples already resident in HBM.  Steps alternate forward / inverse plans on the
+same buffer (inverse(forward(x)) == x, cl_fft.cpp:39-40) so the data stay O(1) instead of
+shrinking by 1/N per step into denormals; both directions are the same kernel.
+The path shards by batches: every rank owns its own 4096 transforms, no data-path
+collective ("weak" scaling, config 5 of BASELINE.json); RCCL only carries the end-of-run
+checksum and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      algorithmic bytes (16 B per complex sample) / average launch
+                duration of the dominant kernel, measured here with HIP events on the launch stream
+  cpu_baseline  the CPU restatement of the reference algorithm (oracle/, "port") timed on the
+                host cores over a bounded sample — a reported baseline, not the target
+Other workloads (--workload rfft | pconv) time configs 3 and 4 with the same machinery.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2c", choices=["c2c", "rfft", "pconv"])
+    ap.add_argument("--variant", type=int, default=-1, help="large-N kernel variant (tuning)")
+    ap.add_argument("--batch", type=int, default=0, help="override batches / channels per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def traffic_from_profiles(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json,
+    written by tools/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE with the gfx950 corrections
+    of MI355X_MICROARCH.md); None when no measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline_c2c(n, sample):
+    """oracle (CPU restatement of the reference's reorder + log2N radix-2 passes) on all host
+    cores over `sample` transforms of the same workload"""
+    import numpy as np
+    from oracle import oracle
+    rng = np.random.default_rng(0)
+    x = (rng.random((sample, n, 2), dtype=np.float32) * 2 - 1).view(np.complex64).reshape(sample, n)
+    oracle.cfft(x[:8], True)                     # warm the thread pool
+    t0 = time.perf_counter()
+    oracle.cfft(x, True)
+    dt = time.perf_counter() - t0
+    return {"value": sample * n / dt / 1e9, "unit": "Gsamples/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "%d transforms of N=%d (%.1f s wall, OpenMP over batches)" % (sample, n, dt)}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import opencl_fft_amd as fa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+        a.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    stream = torch.cuda.Stream(device=dev)
+    K, W = a.steps, a.warmup
+    extra = {}
+
+    if a.workload == "c2c":
+        n, batch = 65536, a.batch or 4096
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        data = torch.rand((batch, n, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        plans = [fa.Clcfft(local, n, True), fa.Clcfft(local, n, False)]
+        for p in plans:
+            assert p.get_error() == 0, p.get_log()
+            if a.variant >= 0:
+                assert p.set_variant(a.variant) == 0
+        units = batch * n                       # complex samples per step per rank
+        alg_bytes = 16.0 * units                # 8 B read + 8 B write per sample
+        step = lambda k: plans[k & 1].exec_device(data, batch, stream.cuda_stream)
+        workload = "c2c N=65536 x %d batches per GPU, float32, in place, device-resident (BASELINE configs[1])" % batch
+        kernel, tkey = plans[0].kernel_name(), "c2c65536"
+        # parity guard (not timed): one transform against the oracle
+        from oracle import oracle
+        x0 = data[0].cpu().numpy().view(np.complex64).reshape(n)
+        with torch.cuda.stream(stream):
+            chk = data[:1].clone()
+            assert plans[0].exec_device(chk, 1, stream.cuda_stream) == 0
+        stream.synchronize()
+        y0 = chk.cpu().numpy().view(np.complex64).reshape(n)
+        ref = oracle.cfft(x0, True)
+        extra["parity_relL2_vs_oracle"] = float(np.linalg.norm(y0.astype(np.complex128) - ref) /
+                                                np.linalg.norm(ref.astype(np.complex128)))
+        metric, unit = "Gsamples/s for batched 1D FFT (N=65536, float32) + achieved HBM GB/s vs peak", "Gsamples/s"
+    elif a.workload == "rfft":
+        size, batch = 16384, a.batch or 8192
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        data = torch.rand((batch, size), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        plans = [fa.Clrfft(local, size, True), fa.Clrfft(local, size, False)]
+        units = batch * size
+        alg_bytes = 8.0 * units                 # 4 B real + 4 B packed complex per real sample, each way
+        step = lambda k: plans[k & 1].exec_device(data, batch, stream.cuda_stream)
+        workload = "r2c then c2r, size=16384 x %d batches per GPU, packed in place (BASELINE configs[2])" % batch
+        kernel, tkey = plans[0].kernel_name(), "rfft16384"
+        metric, unit = "Gsamples/s (real samples) for batched r2c/c2r FFT size=16384", "Gsamples/s"
+    else:
+        pts, cvs, ch = 1024, 96256, a.batch or 256
+        pc = fa.Clpconv(local, cvs, pts, channels=ch)
+        assert pc.get_cl_err() == 0
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        ir = (torch.rand((ch, cvs), generator=g, device=dev) - 0.5) / (cvs ** 0.5)
+        assert pc.push_ir_device(ir) == 0
+        torch.cuda.synchronize()
+        inp = torch.rand((ch, pts), generator=g, device=dev) * 2 - 1
+        out = torch.empty((ch, pts), device=dev)
+        units = ch * pts                        # channel-samples per block
+        nparts = pc.nparts
+        alg_bytes = ch * (2.0 * nparts * pts * 8 + 4 * pts + 8 * pts + 4 * pts + 16 * pts)
+        step = lambda k: pc.process_device(out, inp, None, stream.cuda_stream)
+        workload = ("partitioned convolution, %d channels per GPU, pts=1024, IR 96256 (94 partitions), 48 kHz "
+                    "(BASELINE configs[3])" % ch)
+        kernel, tkey = "k_pconv_mac", "pconv1024x94"
+        metric, unit = "channel-samples/s for partitioned convolution (x1e9)", "Gsamples/s"
+        extra["realtime_ratio_per_channel_denominator_s"] = pts / 48000.0
+
+    with torch.cuda.stream(stream):
+        for k in range(W):
+            assert step(k) == 0
+        stream.synchronize()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+        t0 = time.perf_counter()
+        ev[0].record(stream)
+        for k in range(K):
+            rc = step(k)
+            ev[k + 1].record(stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+    assert rc == 0
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    per_launch_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(K)]
+    fwd_ms = per_launch_ms[0::2] if a.workload != "pconv" else per_launch_ms
+    avg_ms = sum(fwd_ms) / len(fwd_ms)
+
+    # end-of-run checksum over all ranks (validates the sharded run; RCCL only here)
+    chk = (data.double() ** 2).sum().reshape(1) if a.workload != "pconv" else (out.double() ** 2).sum().reshape(1)
+    if world > 1:
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    extra["energy_checksum_all_ranks"] = float(chk.item())
+
+    if rank == 0:
+        value = units * K * world / elapsed / 1e9
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        rec = {
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": dict({"workload": workload, "direction": "steps alternate forward/inverse plans",
+                            "sharding": "batches per rank, no data-path collective", "kernel": kernel,
+                            "variant": a.variant}, **extra),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(tkey),
+                         "kernel": kernel, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not a.no_cpu_baseline and a.workload == "c2c":
+            rec["cpu_baseline"] = cpu_baseline_c2c(65536, 2048)
+        else:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,8 @@
 //                256 MiB Infinity Cache, so HBM sees one read + one write per sample;
 //   k_r2c_pack / k_c2r_unpack, k_reorder  stand-alone forms of the reference's
 //                conv / iconv / reorder kernels.
+#include <cstdlib>
+
 #include "fft_wg.hpp"
 
 namespace clfa {
@@ -293,6 +295,11 @@ static FourVariant four_variant(int variant) {
 
 int fourstep_grid(int logn, int variant, const DeviceInfo &di) {
   (void)logn;
+  // tuning knob for experiments: CLFA_4STEP_GRID=<workgroups>
+  if (const char *e = getenv("CLFA_4STEP_GRID")) {
+    int g = atoi(e);
+    if (g > 0) return g;
+  }
   FourVariant v = four_variant(variant);
   return di.num_cus * v.wg_per_cu;
 }

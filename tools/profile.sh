@@ -1,0 +1,20 @@
+#!/bin/bash
+# Profile bench.py on the GPU box: kernel-trace stats, then separate PMC passes
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# usage: tools/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+set -o pipefail
+TAG=${1:-r01}; shift
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"
+python3 bench.py $ARGS > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err" || exit 1
+echo "== unprofiled"; cat "$OUT/bench_unprofiled.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS > "$OUT/stats.log" 2>&1 || { tail -5 "$OUT/stats.log"; exit 2; }
+echo "== stats done"
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+  D="$OUT/pmc_$(echo $C | tr ' ' '_')"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$D" -- python3 bench.py $ARGS > "$D.log" 2>&1 || { echo "pmc $C failed"; tail -3 "$D.log"; }
+  echo "== pmc $C done"
+done
+python3 tools/pmc_summary.py "$OUT" || true
