@@ -174,6 +174,9 @@ def main():
         t1 = time.perf_counter()
         barrier()
     assert rc == 0
+    if a.workload != "pconv":
+        for p in plans:
+            assert p.sync_check(stream.cuda_stream) == 0, "large-N kernel reported a dependency-wait timeout"
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)

@@ -98,6 +98,9 @@ CLFA_API int clfa_fft_exec_dev(clfa_fft *plan, void *data, long batch, void *str
 CLFA_API size_t clfa_fft_workspace_bytes(const clfa_fft *plan);
 /* name of the HIP kernel that does the work for this plan (for profiles) */
 CLFA_API const char *clfa_fft_kernel_name(const clfa_fft *plan);
+/* waits for `stream` and returns CLFA_SUCCESS, or CLFA_OUT_OF_RESOURCES if the large-N kernel's
+ * bounded dependency waits ever timed out during the plan's last launch (results then invalid) */
+CLFA_API int clfa_fft_sync_check(clfa_fft *plan, void *stream);
 /* tuning: variant id of the large-N kernel (0 = default); returns CLFA_INVALID_VALUE if unknown */
 CLFA_API int clfa_fft_set_variant(clfa_fft *plan, int variant);
 

@@ -122,6 +122,10 @@ class _Plan:
     def set_variant(self, v):
         return lib().clfa_fft_set_variant(self._h, v)
 
+    def sync_check(self, stream=None):
+        """wait for `stream`; non-zero if the large-N kernel's bounded waits ever timed out"""
+        return lib().clfa_fft_sync_check(self._h, stream)
+
     def exec_device(self, data, batch, stream=None):
         """in place on device memory, asynchronous on `stream` (Clcfft::fft(), cl_fft.cpp:138-151)"""
         p, stream = _ptr_stream(data, stream)

@@ -31,6 +31,7 @@ SYMBOLS = [
     ("clfa_fft_workspace_bytes", C.c_size_t, [_vp]),
     ("clfa_fft_kernel_name", C.c_char_p, [_vp]),
     ("clfa_fft_set_variant", C.c_int, [_vp, C.c_int]),
+    ("clfa_fft_sync_check", C.c_int, [_vp, _vp]),
     ("clfa_reorder_dev", C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_long, _vp]),
     ("clfa_pconv_create", C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
     ("clfa_pconv_destroy", None, [_vp]),

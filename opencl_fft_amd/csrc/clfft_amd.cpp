@@ -137,7 +137,7 @@ struct clfa_fft {
   int variant = 0;
   char log[2048];
   hipStream_t stream = nullptr;
-  DevBuf half, w2, four, scratch, stage;
+  DevBuf half, w2, four, scratch, stage, ctl;
   FftTables tabs;
 };
 
@@ -292,7 +292,9 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
     p->tabs.four = (const cpx *)p->four.p;
     size_t sbytes = (size_t)fourstep_grid(p->logn, p->variant, p->di) * n * sizeof(cpx);
+    if (p->variant == kVariantCoop) sbytes = coop_scratch_bytes(p->logn);
     if ((e = p->scratch.ensure(sbytes))) return e;
+    if ((e = p->ctl.ensure(coop_ctl_bytes()))) return e;
   }
   if (real) {
     fill_w2(h, n, fwd ? -1.f : 1.f);
@@ -338,6 +340,7 @@ void clfa_fft_destroy(clfa_fft *p) {
   p->four.release();
   p->scratch.release();
   p->stage.release();
+  p->ctl.release();
   delete p;
 }
 
@@ -351,17 +354,29 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
 }
 
 int clfa_fft_set_variant(clfa_fft *p, int variant) {
-  if (!p || variant < 0 || variant > 6) return CLFA_INVALID_VALUE;
+  if (!p || variant < 0 || variant > kVariantCoop) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   p->variant = variant;
   if (p->logn > kLdsMaxLog) {
     HIP_TRY(hipSetDevice(p->di.device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     size_t sbytes = (size_t)fourstep_grid(p->logn, variant, p->di) * p->n * sizeof(cpx);
+    if (variant == kVariantCoop) sbytes = coop_scratch_bytes(p->logn);
     int e = p->scratch.ensure(sbytes);
     if (e) return e;
   }
   return CLFA_SUCCESS;
+}
+
+int clfa_fft_sync_check(clfa_fft *p, void *stream) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  HIP_TRY(hipSetDevice(p->di.device));
+  hipStream_t s = (hipStream_t)stream;
+  unsigned err = 0;
+  if (p->logn > kLdsMaxLog && p->variant == kVariantCoop && p->ctl.p) HIP_TRY(coop_read_error(p->ctl.p, &err, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return err ? CLFA_OUT_OF_RESOURCES : CLFA_SUCCESS;
 }
 
 int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
@@ -379,7 +394,10 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
     return CLFA_SUCCESS;
   }
   if (p->real && !p->fwd) HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, p->n, batch, s));
-  HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, p->variant, d, (cpx *)p->scratch.p, p->tabs, batch, p->di, s));
+  if (p->variant == kVariantCoop)
+    HIP_TRY(launch_fft_coop(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));
+  else
+    HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, p->variant, d, (cpx *)p->scratch.p, p->tabs, batch, p->di, s));
   if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, p->n, batch, s));
   return CLFA_SUCCESS;
 }

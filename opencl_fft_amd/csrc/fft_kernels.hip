@@ -211,21 +211,33 @@ __device__ __forceinline__ void four_phase1(const cpx *__restrict__ src, cpx *__
 
 // phase 2 of one slice: row block rb of `src` (rows k1, contiguous n2) ->
 // N2-point FFT along each row -> dst[k1 + N1*k2] (natural order of the result)
-template <int LOGN, bool FWD, bool SCALE, bool NT>
+// 8-byte load that bypasses the CU's vector L1 (global_load_dwordx2 ... sc1): data another
+// CU of the same XCD has stored is served from the shared L2 (MI355X_MICROARCH.md, workgroup
+// dispatch & inter-workgroup visibility)
+__device__ __forceinline__ cpx ld_sc1(const cpx *p) {
+  unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+  return *reinterpret_cast<cpx *>(&raw);
+}
+
+template <int LOGN, bool FWD, bool SCALE, bool NT, bool SC1 = false>
 __device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__restrict__ dst, int rb, int l,
-                                            const cpx *tab2, cpx *sx) {
+                                            const cpx *tab2, cpx *sx, unsigned *read_done = nullptr) {
   using G = FourGeom<LOGN>;
   cpx v[16];
   {
     const int tf = l % G::T2, row = l / G::T2;
     const cpx *p = src + (long)(rb * G::R2 + row) * G::N2 + tf;
 #pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = p[G::T2 * e];
+    for (int e = 0; e < 16; e++) v[e] = SC1 ? ld_sc1(p + G::T2 * e) : p[G::T2 * e];
     pass_compute<G::LOGN2, 4, 0, FWD>(v, tf, tab2);
     __syncthreads();
     cpx *xr = sx + row * G::S2;
     pass_scatter<G::LOGN2, 4, 0>(v, tf, [&](int q, cpx val) { xr[lds_pad(q)] = val; });
     __syncthreads();
+    // every lane has consumed its loads from `src`: the scratch slot may be reused
+    if (read_done != nullptr && l == 0)
+      (void)__hip_atomic_fetch_add(read_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // in the XCD's L2
   }
   // the last pass runs with rows on the fast lane index so that the transposed
   // store below is contiguous across lanes
@@ -282,14 +294,16 @@ struct FourVariant {
   int wg_per_cu;
 };
 static FourVariant four_variant(int variant) {
+  // {slices of 256 lanes per workgroup, non-temporal streaming, workgroups per CU}.
+  // Measured on MI355X, N = 65536 x 4096 (profiles/): 0 is the fastest (1.45 ms).
   switch (variant) {
     case 1: return {4, false, 1};
     case 2: return {2, false, 2};
-    case 3: return {2, true, 2};
+    case 3: return {4, true, 1};
     case 4: return {1, false, 4};
     case 5: return {1, false, 2};
     case 6: return {2, false, 1};
-    default: return {4, true, 1};  // 0
+    default: return {2, true, 2};  // 0
   }
 }
 
@@ -342,6 +356,266 @@ hipError_t launch_fft_4step(int logn, bool fwd, bool scale, int variant, cpx *da
 }
 
 const char *name_fft_4step(int, bool, int) { return "k_fft_4step"; }
+
+
+// ---------------------------------------------------------------------------------
+// XCD-cooperative four-step FFT (the default for n = 2^14 .. 2^16)
+// ---------------------------------------------------------------------------------
+// Measured on MI355X (profiles/membench_r01.txt): a per-workgroup 512 KiB scratch costs a
+// full extra pass (3.6 TB/s algorithmic at best), but scratch that stays hot in the XCD's
+// 4 MiB L2 is free (5.2 TB/s, the copy rate) when the streamed input/output use
+// non-temporal accesses.  So the 256-lane workgroups of one XCD share a few scratch slots
+// and pull tasks — one column block (phase 1) or one row block (phase 2) of a transform —
+// from that XCD's queue in an order that keeps ~3-6 transforms live per XCD:
+//     P1(0) .. P1(LAG-1)  P1(LAG) P2(0)  P1(LAG+1) P2(1) ...   (groups of NCB = NRB tasks)
+// so P2(i) is queued 2*LAG+1 groups after P1(i): far enough that its inputs are normally
+// complete when it is dequeued, near enough that the live scratch stays in the L2.
+// A phase-2 task waits until all column blocks of its transform are stored, a phase-1
+// task until the previous user of its slot has been read.  A task waits only for tasks
+// that precede it in the queue, so the earliest unfinished task can always run: no
+// deadlock whatever the grid, residency or dispatch order.  Nothing relies on
+// workgroup -> XCD placement: the XCD is read from HW_REG_XCC_ID and every queue,
+// counter and scratch slot is private to the XCD that reads that id; counters are
+// agent-scope atomics; scratch is written with plain stores (they stay in the L2),
+// drained with s_waitcnt vmcnt(0) before the counter add, and read with sc1 loads.
+constexpr int kCoopMaxSlots = 16;
+constexpr unsigned kCoopNone = 0xFFFFFFFFu;
+constexpr unsigned kCoopSpinLimit = 1u << 20;
+
+// one record per scratch slot, read with a single pair of 8-byte loads per task.  Every
+// hot word sits on its own 128-byte line: atomics and polls to one line serialise at the
+// memory side (~11 ns each, MI355X_MICROARCH.md "fanin"/"dequeue").
+struct alignas(128) CoopSlot {
+  unsigned c1;   // finished phase-1 tasks on this slot (monotonic over the launch)
+  unsigned c2;   // phase-2 tasks that have finished READING this slot
+  unsigned tag;  // local transform index + 1 of the current owner
+  unsigned xf;   // its global transform index + 1
+};
+struct alignas(128) CoopWord {
+  unsigned v;
+};
+struct alignas(256) CoopXcd {
+  CoopWord head;    // task queue head
+  CoopWord draws;   // owner tasks that have drawn their global transform index (in queue order)
+  CoopWord endinv;  // 0xFFFFFFFF - (first local index without a transform); 0 = not known yet
+  CoopSlot slot[kCoopMaxSlots];
+};
+struct CoopCtl {
+  CoopXcd x[8];
+  CoopWord next_transform;
+  CoopWord error;
+};
+size_t coop_ctl_bytes() { return sizeof(CoopCtl); }
+
+// queue group g -> (phase, local transform index)
+__device__ __forceinline__ void coop_decode(unsigned g, unsigned lag, bool &p1, unsigned &i) {
+  if (g < lag) {
+    p1 = true;
+    i = g;
+  } else {
+    const unsigned h = g - lag;
+    p1 = !(h & 1u);
+    i = p1 ? lag + h / 2 : h / 2;
+  }
+}
+
+// Per-XCD control words are only ever touched by workgroups that read the same XCC_ID, i.e.
+// by clients of ONE L2.  Updates are read-modify-writes at workgroup scope: no sc1 bit, so
+// they execute in that L2 (a few hundred ns) instead of at the memory side (1-2 us).
+// Polls are sc1 loads: they bypass the vector L1 and are served by the same L2.  (A
+// `fetch_add(p, 0)` poll is folded by the compiler into an sc0 load that hits stale L1
+// lines — seen in the ISA and on hardware — so polls are written as agent-scope atomic loads.)
+#define CLFA_XCD_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+__device__ __forceinline__ unsigned xcd_read(unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned xcd_add(unsigned *p, unsigned v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
+}
+__device__ __forceinline__ void xcd_write(unsigned *p, unsigned v) {
+  (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
+}
+__device__ __forceinline__ CoopSlot coop_load_slot(CoopSlot *r) {
+  const unsigned long long a = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->c1), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->tag), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  CoopSlot v;
+  v.c1 = (unsigned)a;
+  v.c2 = (unsigned)(a >> 32);
+  v.tag = (unsigned)b;
+  v.xf = (unsigned)(b >> 32);
+  return v;
+}
+
+template <int LOGN, bool FWD, bool SCALE>
+__global__ __launch_bounds__(256, 3) void k_fft_coop(cpx *__restrict__ data, cpx *__restrict__ scratch,
+                                                     const cpx *__restrict__ tabs_g, long batch, CoopCtl *ctl,
+                                                     int nslots, int lag) {
+  using G = FourGeom<LOGN>;
+  static_assert(G::NCB == G::NRB, "task groups of both phases have the same size");
+  constexpr unsigned TPG = G::NCB;
+  // LDS tables: [lo | hi | (half N1 unless it is a prefix of hi)].  hi = W_HI^k is also the
+  // half table of every inner length that equals HI, which keeps the block under 40 KiB.
+  constexpr bool A1 = (G::N1 == G::HI), A2 = (G::N2 == G::HI);
+  static_assert(A2, "the row length equals the high twiddle table length for n = 2^14..2^16");
+  constexpr int CTABS = G::LO + G::HI + (A1 ? 0 : G::N1 / 2);
+  __shared__ cpx s_tabs[CTABS];
+  __shared__ cpx s_x[G::SL];
+  __shared__ unsigned s_q, s_xf;
+  const int tid = threadIdx.x;
+  {
+    const cpx *g_lo = tabs_g + G::N1 / 2 + G::N2 / 2;
+    for (int i = tid; i < G::LO + G::HI; i += 256) s_tabs[i] = g_lo[i];
+    if constexpr (!A1)
+      for (int i = tid; i < G::N1 / 2; i += 256) s_tabs[G::LO + G::HI + i] = tabs_g[i];
+  }
+  const cpx *tlo = s_tabs, *thi = s_tabs + G::LO;
+  const cpx *tab2 = thi, *tab1 = A1 ? thi : s_tabs + G::LO + G::HI;
+  const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;  // hwreg(HW_REG_XCC_ID, 0, 4)
+  CoopXcd *c = &ctl->x[xcc];
+  cpx *sbase = scratch + (long)xcc * nslots * G::N;
+
+  unsigned *pend = nullptr;  // lane 0: phase-1 completion counter still to be signalled
+
+  for (;;) {
+    // every wave drains the stores of its previous task; only then may its completion be
+    // signalled — and it must be signalled BEFORE this workgroup waits on anything, because
+    // the task it is about to resolve may depend on that very completion
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      if (pend) (void)xcd_add(pend, 1u);
+      pend = nullptr;
+      // ---- draw and resolve the next task --------------------------------------
+      // (drawing it earlier, during the previous task, would hide this round trip but
+      // doubles the queue window each workgroup occupies; measured 2x slower)
+      const unsigned q = xcd_add(&c->head.v, 1u);
+      const unsigned g = q / TPG, idx = q % TPG;
+      bool p1;
+      unsigned i;
+      coop_decode(g, (unsigned)lag, p1, i);
+      const unsigned slot = i % nslots, use = i / nslots;
+      CoopSlot *rec = &c->slot[slot];
+      unsigned xf = kCoopNone, n = 0;
+      bool known_end = i >= 0xFFFFFFFFu - xcd_read(&c->endinv.v);
+      if (known_end) {
+        // past the end of this XCD's share of the batch: nothing to do, nothing to wait for
+      } else if (p1 && idx == 0) {
+        // owner task of local transform i.  Global indices are drawn in queue order per XCD
+        // (ticket `draws`), so "the first local index that got none" is well defined.
+        while (xcd_read(&c->draws.v) != i) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++n > kCoopSpinLimit) {
+            __hip_atomic_store(&ctl->error.v, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        const unsigned gi = __hip_atomic_fetch_add(&ctl->next_transform.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((long)gi >= batch)  // max of the complement = smallest local index that got none
+          __hip_atomic_fetch_max(&c->endinv.v, 0xFFFFFFFFu - i, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
+        xcd_write(&c->draws.v, i + 1);
+        if ((long)gi < batch) {
+          // wait until the slot's previous user has been read, then publish
+          while (use > 0 && coop_load_slot(rec).c2 < TPG * use) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++n > kCoopSpinLimit) {
+              __hip_atomic_store(&ctl->error.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+          xf = gi + 1;
+          (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&rec->tag),
+                                      ((unsigned long long)xf << 32) | (unsigned long long)(i + 1), __ATOMIC_RELAXED,
+                                      CLFA_XCD_SCOPE);
+        }
+      } else {
+        for (;;) {
+          const CoopSlot v = coop_load_slot(rec);
+          if (v.tag == i + 1 && (p1 || v.c1 >= TPG * (use + 1))) {
+            xf = v.xf;
+            break;
+          }
+          if (i >= 0xFFFFFFFFu - xcd_read(&c->endinv.v)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++n > kCoopSpinLimit) {  // never hang the GPU: flag the launch and drop the task
+            __hip_atomic_store(&ctl->error.v, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      s_q = q;
+      s_xf = xf;
+    }
+    __syncthreads();
+    const unsigned q = s_q, xf = s_xf;
+    const unsigned g = q / TPG, idx = q % TPG;
+    bool p1;
+    unsigned i;
+    coop_decode(g, (unsigned)lag, p1, i);
+    CoopSlot *rec = &c->slot[i % nslots];
+    if (xf == kCoopNone) {
+      if (p1) continue;  // past the end: phase-2 tasks of earlier transforms still follow in the queue
+      break;
+    }
+    cpx *x = data + (long)(xf - 1) * G::N;
+    cpx *mid = sbase + (long)(i % nslots) * G::N;
+    if (p1) {
+      four_phase1<LOGN, FWD, true>(x, mid, (int)idx, tid, tab1, tlo, thi, s_x);
+      if (tid == 0) pend = &rec->c1;  // signalled once every wave has drained its stores
+    } else {
+      four_phase2<LOGN, FWD, SCALE, true, true>(mid, x, (int)idx, tid, tab2, s_x, &rec->c2);
+    }
+  }
+}
+
+int coop_slots() {
+  if (const char *e = getenv("CLFA_COOP_SLOTS")) {
+    int v = atoi(e);
+    if (v >= 2 && v <= kCoopMaxSlots) return v;
+  }
+  return 6;
+}
+size_t coop_scratch_bytes(int logn) { return (size_t)8 * kCoopMaxSlots * sizeof(cpx) << logn; }
+
+template <int LOGN>
+static hipError_t launch_coop_n(bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
+                                long batch, const DeviceInfo &di, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(ctl, 0, sizeof(CoopCtl), s);
+  if (e != hipSuccess) return e;
+  int grid = di.num_cus * 4;
+  if (const char *g = getenv("CLFA_COOP_GRID")) {
+    int v = atoi(g);
+    if (v > 0) grid = v;
+  }
+  const int ns = coop_slots();
+  int lag = 2;
+  if (const char *l = getenv("CLFA_COOP_LAG")) {
+    int v = atoi(l);
+    if (v >= 1 && v <= 8) lag = v;
+  }
+  CoopCtl *c = (CoopCtl *)ctl;
+  if (fwd && scale) hipLaunchKernelGGL((k_fft_coop<LOGN, true, true>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns, lag);
+  else if (fwd) hipLaunchKernelGGL((k_fft_coop<LOGN, true, false>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns, lag);
+  else hipLaunchKernelGGL((k_fft_coop<LOGN, false, false>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns, lag);
+  return hipGetLastError();
+}
+
+hipError_t launch_fft_coop(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
+                           long batch, const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  switch (logn) {
+    case 14: return launch_coop_n<14>(fwd, scale, data, scratch, ctl, t, batch, di, s);
+    case 15: return launch_coop_n<15>(fwd, scale, data, scratch, ctl, t, batch, di, s);
+    case 16: return launch_coop_n<16>(fwd, scale, data, scratch, ctl, t, batch, di, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// reads the error word of the last cooperative launch (0 = no spin ever timed out)
+hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s) {
+  return hipMemcpyAsync(err, &((const CoopCtl *)ctl)->error.v, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+}
 
 // ---------------------------------------------------------------------------------
 // stand-alone pack / unpack / reorder

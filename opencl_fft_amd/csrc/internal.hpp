@@ -36,6 +36,14 @@ hipError_t launch_fft_4step(int logn, bool fwd, bool scale, int variant, cpx *da
                             const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
 const char *name_fft_4step(int logn, bool fwd, int variant);
 int fourstep_split(int logn, int *logn1, int *logn2, int *loglo);
+// XCD-cooperative four-step (the default large-N path): scratch = 8 XCDs x slots x n complex,
+// ctl = a small control block zeroed on the stream before every launch
+constexpr int kVariantCoop = 7;
+size_t coop_ctl_bytes();
+size_t coop_scratch_bytes(int logn);
+hipError_t launch_fft_coop(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
+                           long batch, const DeviceInfo &di, hipStream_t s);
+hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s);
 
 // stand-alone pack / unpack (reference kernels conv / iconv) for M above the LDS path
 hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
