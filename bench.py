@@ -92,6 +92,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    from opencl_fft_amd.dist import ShardedBatch
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -101,7 +103,12 @@ def main():
     extra = {}
 
     if a.workload == "c2c":
-        n, batch = 65536, a.batch or 4096
+        n = 65536
+        # weak scaling: 4096 transforms per GPU (config 5 = 32768 over 8 GPUs); the global batch is
+        # split into contiguous blocks, rank r owns [start, start+count)
+        shard = ShardedBatch((a.batch or 4096) * world, rank, world)
+        batch = shard.count
+        extra["global_batch"], extra["shard_start"] = shard.total, shard.start
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         data = torch.rand((batch, n, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1
         plans = [fa.Clcfft(local, n, True), fa.Clcfft(local, n, False)]

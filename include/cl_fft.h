@@ -1,0 +1,66 @@
+// cl_fft.h — drop-in for the reference's cl_fft.h (class surface cl_fft.h:22-112):
+// same namespace, class names, constructor and method signatures, integer OpenCL
+// status codes; computation by libclfft_amd.so (hand-written HIP for gfx950).
+// Link with -lcl_fft -lclfft_amd.
+#ifndef __CL_FFT_H__
+#define __CL_FFT_H__
+
+#include <complex>
+#include <iostream>
+
+#include "clfft_amd/cl_compat.h"
+
+namespace cl_fft {
+
+const double PI = 3.141592653589793;       // cl_fft.h:24
+const char *cl_error_string(int err);      // cl_fft.h:25
+
+/** Complex to Complex FFT class (cl_fft.h:29-70) */
+class Clcfft {
+ protected:
+  int N;
+  bool forward;
+  clfa_fft *plan;   // replaces the reference's context / queue / program / buffers
+  int cl_err;
+
+ public:
+  /** device_id - device handle; size - DFT size (N); fwd - direction */
+  Clcfft(cl_device_id device_id, int size, bool fwd = true);
+  virtual ~Clcfft();
+  /** DFT operation (in-place), c - N complex numbers */
+  virtual int transform(std::complex<float> *c);
+  /** batched extension: `batch` contiguous arrays of N complex numbers */
+  int transform(std::complex<float> *c, long batch);
+  /** device-resident extension: in place on device memory, asynchronous on a hipStream_t */
+  int transform_device(void *data, long batch, void *stream = 0);
+  /** Get setup error code */
+  int get_error() { return cl_err; }
+  /** Get compilation log (setup diagnostics here; nothing is JIT-compiled) */
+  const char *get_log();
+
+ private:
+  Clcfft(const Clcfft &);
+  Clcfft &operator=(const Clcfft &);
+
+ protected:
+  Clcfft(cl_device_id device_id, int size, bool fwd, bool real);
+};
+
+/** Real to Complex FFT class (cl_fft.h:74-111) */
+class Clrfft : public Clcfft {
+ public:
+  Clrfft(cl_device_id device_id, int size, bool fwd);
+  virtual ~Clrfft();
+  /** c - N/2 complex numbers, r - N real numbers; in place if both point to the same memory */
+  int transform(std::complex<float> *c, float *r);
+  /** in-place form */
+  virtual int transform(std::complex<float> *c) {
+    float *r = reinterpret_cast<float *>(c);
+    return transform(c, r);
+  }
+  /** batched extension */
+  int transform(std::complex<float> *c, float *r, long batch);
+};
+}  // namespace cl_fft
+
+#endif

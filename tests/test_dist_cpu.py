@@ -1,0 +1,73 @@
+"""The N>1 path on CPU: 2 processes, gloo backend, 127.0.0.1.  Each rank takes its contiguous
+block of the batch axis (opencl_fft_amd.dist.shard_range), transforms it (with the oracle here —
+there is no GPU), and the ranks reduce a checksum and the max time exactly as bench.py does
+with RCCL.  The union of the shards must equal the unsharded result bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from opencl_fft_amd.dist import shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 8, 4096, 32768, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+            assert spans[-1][0] + spans[-1][1] == total
+            counts = [c for _, c in spans]
+            assert max(counts) - min(counts) <= 1
+    assert shard_range(32768, 3, 8) == (12288, 4096)          # config 5: 4096 per GPU
+    with pytest.raises(ValueError):
+        shard_range(8, 8, 8)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, n, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opencl_fft_amd.dist import ShardedBatch
+    from oracle import oracle
+    from tests import util
+    sb = ShardedBatch(total)
+    assert (sb.rank, sb.world) == (rank, world)
+    x = util.lcg_complex(2024, total * n).reshape(total, n)         # every rank can derive any batch
+    sb.barrier()
+    y = oracle.cfft(x[sb.slice()], True) if sb.count else np.zeros((0, n), np.complex64)
+    energy = float(np.sum(np.abs(y.astype(np.complex128)) ** 2))
+    tot = float(sb.reduce_sum(energy).item())
+    tmax = sb.reduce_max(1.0 + rank)
+    np.save(os.path.join(out_dir, "y%d.npy" % rank), y)
+    np.save(os.path.join(out_dir, "meta%d.npy" % rank), np.array([tot, tmax, sb.start, sb.count]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [10, 7])
+def test_two_rank_gloo_sharded_fft(tmp_path, total):
+    import torch.multiprocessing as mp
+    from oracle import oracle
+    from tests import util
+    world, n = 2, 256
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, n, str(tmp_path)), nprocs=world, join=True)
+    x = util.lcg_complex(2024, total * n).reshape(total, n)
+    want = oracle.cfft(x, True)
+    parts = [np.load(tmp_path / ("y%d.npy" % r)) for r in range(world)]
+    metas = [np.load(tmp_path / ("meta%d.npy" % r)) for r in range(world)]
+    got = np.concatenate(parts, axis=0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    e = float(np.sum(np.abs(want.astype(np.complex128)) ** 2))
+    for m in metas:
+        assert abs(m[0] - e) <= 1e-9 * e          # checksum of checksums agrees on every rank
+        assert m[1] == 2.0                        # max over ranks of (1 + rank)
+    assert [int(m[3]) for m in metas] == [c for _, c in (shard_range(total, r, world) for r in range(world))]
