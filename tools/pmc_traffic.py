@@ -1,0 +1,53 @@
+"""Turn tools/profile.sh output into the committed evidence: profiles/<tag>/{kernel_stats.csv,
+pmc_summary.json, summary.txt} and the per-launch HBM-side traffic in profiles/traffic.json.
+
+Traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch of the dominant kernel.  The factor 2 is the
+gfx950 correction of MI355X_MICROARCH.md ("FETCH_SIZE reports exactly 1/2 of the bytes of a wide
+coalesced streaming read"), re-calibrated here on a kernel of known byte count (torch's 2 GiB
+elementwise kernels in the same trace read 1.00 GiB FETCH_SIZE for 2 GiB read; WRITE_SIZE exact).
+These counters sit at the L2 <-> fabric interface: Infinity-Cache hits are included."""
+import csv, glob, json, os, shutil, sys
+
+def main(src, tag, key, kernel_substr, root):
+    dst = os.path.join(root, "profiles", tag)
+    os.makedirs(dst, exist_ok=True)
+    for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+    for f in ("bench_unprofiled.json", "summary.json"):
+        if os.path.exists(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "summary.json" else "pmc_summary.json"))
+    acc = {}
+    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    def upper_mean(v):          # drop small auxiliary launches (parity probe): keep the upper 3/4
+        v = sorted(v)[len(v) // 4:]
+        return sum(v) / len(v)
+    out = {"kernel": kernel_substr, "source": "profiles/%s (rocprofv3 --pmc, separate passes)" % tag}
+    if "FETCH_SIZE" in acc and "WRITE_SIZE" in acc:
+        fetch_kb, write_kb = upper_mean(acc["FETCH_SIZE"]), upper_mean(acc["WRITE_SIZE"])
+        out.update({"FETCH_SIZE_KiB": fetch_kb, "WRITE_SIZE_KiB": write_kb,
+                    "read_bytes": 2 * 1024 * fetch_kb, "write_bytes": 1024 * write_kb,
+                    "hbm_bytes_per_launch": 2 * 1024 * fetch_kb + 1024 * write_kb})
+    for c in ("TCC_HIT_sum", "TCC_MISS_sum"):
+        if c in acc:
+            out[c] = upper_mean(acc[c])
+    tj = os.path.join(root, "profiles", "traffic.json")
+    allt = json.load(open(tj)) if os.path.exists(tj) else {}
+    allt[key] = out
+    json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
+    with open(os.path.join(dst, "summary.txt"), "w") as fh:
+        fh.write("tag %s  kernel %s\n" % (tag, kernel_substr))
+        for k, v in out.items():
+            fh.write("%s: %s\n" % (k, v))
+        ks = os.path.join(dst, "kernel_stats.csv")
+        if os.path.exists(ks):
+            fh.write("\nrocprofv3 --kernel-trace --stats (top kernels):\n")
+            for i, r in enumerate(csv.DictReader(open(ks))):
+                if i < 6:
+                    fh.write("  %-90s calls %s avg_ns %s\n" % (r["Name"][:90], r["Calls"], r["AverageNs"]))
+    print(open(os.path.join(dst, "summary.txt")).read())
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
