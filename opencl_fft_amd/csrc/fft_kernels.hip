@@ -20,6 +20,31 @@ namespace clfa {
 // single-workgroup LDS FFT
 // ---------------------------------------------------------------------------------
 
+// Global loads of one transform into registers, in the order the first stage wants them:
+//   C2C / R2C : v[e] = x[t + T*e]                         (coalesced, T apart)
+//   C2R       : v[2k] = x[i], v[2k+1] = x[N-i], i = t + T*k (the pairs of the reference's iconv);
+//               pair 0 of lane 0 is (x[0], x[N/2])
+template <int LOGN, int MODE>
+__device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const cpx *x, int t) {
+  // No predicates on purpose: callers clamp the transform index instead.  Loads inside
+  // exec-masked or even uniform branches make hipcc lose count of them and wait vmcnt(0) at the
+  // join, i.e. for the prefetch it has just issued (seen in the ISA); straight-line loads get a
+  // counted s_waitcnt vmcnt(N) and stay in flight behind the passes.
+  using G = LdsGeom<LOGN>;
+  constexpr int N = G::N, E = G::E, T = G::T;
+  if constexpr (MODE == MODE_C2R) {
+#pragma unroll
+    for (int k = 0; k < E / 2; k++) {
+      const int i = t + T * k;
+      v[2 * k] = x[i];
+      v[2 * k + 1] = x[i == 0 ? N / 2 : N - i];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; e++) v[e] = x[t + T * e];
+  }
+}
+
 template <int LOGN, bool FWD, int MODE, bool SCALE>
 __global__ __launch_bounds__(LdsGeom<LOGN>::WG) void k_fft_lds(cpx *__restrict__ data,
                                                               const cpx *__restrict__ tab_g,
@@ -32,38 +57,58 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG) void k_fft_lds(cpx *__restrict__
   const int tid = threadIdx.x;
   const int f = tid / T, t = tid % T;
   for (int i = tid; i < N / 2; i += WG) s_tab[i] = tab_g[i];
-  __syncthreads();
   cpx *xb = s_x + f * G::PADN;
 
+  // pack / unpack twiddles of this lane's pairs are the same for every transform
+  constexpr int NP = (MODE == MODE_C2C) ? 1 : (E / 2 > 0 ? E / 2 : 1);
+  cpx w2r[NP];
+  if constexpr (MODE != MODE_C2C) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) w2r[k] = w2_g[t + T * k];
+  }
+  __syncthreads();
+
   const long groups = (batch + FPW - 1) / FPW;
+  long g = blockIdx.x;
+  cpx v[E], vn[E];
+  if (g >= groups) return;   // whole workgroup (uniform): launchers never over-provision the grid
+  {
+    const long b = g * FPW + f;
+    lds_fft_load<LOGN, MODE>(v, data + (b < batch ? b : batch - 1) * (long)N, t);
+#pragma unroll
+    for (int e = 0; e < E; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
+  }
 #pragma unroll 1
-  for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+  for (; g < groups; g += gridDim.x) {
     const long b = g * FPW + f;
     const bool active = b < batch;
-    cpx *x = data + (active ? b : 0) * (long)N;
-    cpx v[E];
+    cpx *x = data + (active ? b : batch - 1) * (long)N;
+    // software prefetch: the next transform's loads fly while this one is in the passes.
+    // Always issued (index clamped to the last transform) so that it is straight-line code.
+    {
+      long gn = g + gridDim.x;
+      gn = gn < groups ? gn : groups - 1;
+      const long bn = gn * FPW + f;
+      lds_fft_load<LOGN, MODE>(vn, data + (bn < batch ? bn : batch - 1) * (long)N, t);
+    }
     if constexpr (MODE == MODE_C2R) {
-      // fused reference `iconv` on the way in
+      // fused reference `iconv` (cl_fft.cpp:192-205) on the way in
       __syncthreads();
-      if (active) {
-        for (int i = t; i < N / 2; i += T) {
-          if (i == 0) {
-            cpx c0 = x[0];
-            xb[0] = mk(c0.x + c0.y, c0.x - c0.y);
-            xb[lds_pad(N / 2)] = x[N / 2];
-          } else {
-            cpx oi, oj;
-            c2r_pair(x[i], x[N - i], w2_g[i], oi, oj);
-            xb[lds_pad(i)] = oi;
-            xb[lds_pad(N - i)] = oj;
-          }
+#pragma unroll
+      for (int k = 0; k < E / 2; k++) {
+        const int i = t + T * k;
+        if (i == 0) {
+          xb[0] = mk(v[0].x + v[0].y, v[0].x - v[0].y);
+          xb[lds_pad(N / 2)] = v[1];
+        } else {
+          cpx oi, oj;
+          c2r_pair(v[2 * k], v[2 * k + 1], w2r[k], oi, oj);
+          xb[lds_pad(i)] = oi;
+          xb[lds_pad(N - i)] = oj;
         }
       }
       __syncthreads();
       pass_gather<LOGN, G::LOGE>(v, t, [&](int p) { return xb[lds_pad(p)]; });
-    } else {
-#pragma unroll
-      for (int e = 0; e < E; e++) v[e] = active ? x[t + T * e] : mk(0.f, 0.f);
     }
 
     wg_passes<LOGN, G::LOGE, 0, FWD>(v, t, s_tab, xb);
@@ -74,31 +119,42 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG) void k_fft_lds(cpx *__restrict__
       for (int e = 0; e < E; e++) v[e] = cscale(v[e], inv);
     }
 
+    // Stores are unconditional as well (same reason as the loads).  Lanes of a ragged last
+    // group whose transform index is past the batch were clamped to the LAST transform: they
+    // loaded the same input in the same instruction as its owner and store bit-identical output.
+    (void)active;
     if constexpr (MODE == MODE_R2C) {
-      // fused reference `conv` on the way out
+      // fused reference `conv` (cl_fft.cpp:178-191) on the way out
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < E; e++) xb[lds_pad(t + T * e)] = v[e];
       __syncthreads();
-      if (active) {
-        for (int i = t; i < N / 2; i += T) {
-          if (i == 0) {
-            cpx z = xb[0];
-            x[0] = mk((z.x + z.y) * .5f, (z.x - z.y) * .5f);
-            x[N / 2] = xb[lds_pad(N / 2)];
-          } else {
-            cpx oi, oj;
-            r2c_pair(xb[lds_pad(i)], xb[lds_pad(N - i)], w2_g[i], oi, oj);
-            x[i] = oi;
-            x[N - i] = oj;
-          }
+#pragma unroll
+      for (int k = 0; k < E / 2; k++) {
+        // branch-free: pair 0 is (bin 0 packed DC/Nyquist, bin N/2 copied through), selected by value
+        const int i = t + T * k;
+        const int j = i == 0 ? N / 2 : N - i;
+        const cpx ci = xb[lds_pad(i)], cj = xb[lds_pad(j)];
+        cpx oi, oj;
+        r2c_pair(ci, cj, w2r[k], oi, oj);
+        if (i == 0) {
+          oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
+          oj = cj;
         }
+        x[i] = oi;
+        x[j] = oj;
       }
     } else {
-      if (active) {
 #pragma unroll
-        for (int e = 0; e < E; e++) x[t + T * e] = v[e];
-      }
+      for (int e = 0; e < E; e++) x[t + T * e] = v[e];
+    }
+    // Consume the prefetch HERE, in straight-line code after the stores: hipcc then waits with an
+    // exact s_waitcnt vmcnt(<stores still in flight>).  If the first use were at the loop top, the
+    // wait would be merged with the loop-entry path and drain this iteration's stores as well.
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
+      v[e] = vn[e];
     }
   }
 }
@@ -108,9 +164,19 @@ static hipError_t launch_lds_one(cpx *data, const FftTables &t, long batch, cons
                                  hipStream_t s) {
   using G = LdsGeom<LOGN>;
   long groups = (batch + G::FPW - 1) / G::FPW;
-  // persistent-ish grid: enough workgroups to fill the chip several times over,
-  // grid-stride over the rest so the LDS twiddle table is loaded once per workgroup
-  long cap = (long)di.num_cus * 16;
+  // persistent grid: exactly the workgroups that are resident at once (occupancy x CUs), each
+  // grid-striding over many transforms, so the LDS twiddle table is loaded once per workgroup
+  // and every transform but the first is software-prefetched
+  static int occ = 0;  // per instantiation
+  if (occ == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fft_lds<LOGN, FWD, MODE, SCALE>, G::WG, 0) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = 1;
+    }
+    occ = nb;
+  }
+  long cap = (long)di.num_cus * occ;
   int grid = (int)(groups < cap ? groups : cap);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_fft_lds<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(G::WG), 0, s, data, t.half, t.w2,
