@@ -151,6 +151,8 @@ struct clfa_pconv {
   DevBuf half, w2f, w2i;             // tables (cl_conv.cpp:263-287)
   DevBuf ringA, ringB, acc, tail;    // spec1, spec2, in1-as-accumulator, olap tail
   DevBuf in1, in2, out, ir;          // staging for the host entry points
+  DevBuf four, scratch, work;        // partitions above the LDS sizes: large-N tables, scratch, work frames
+  FftTables big;
 };
 
 struct clfa_dconv {
@@ -486,11 +488,29 @@ static int pconv_setup(clfa_pconv *p, int device, int cvs, int pts, int channels
   if ((e = upload(p->w2f, h.data(), sizeof(cpx) * pts))) return e;
   fill_w2(h, pts, 1.f);            // cl_conv.cpp:282-287
   if ((e = upload(p->w2i, h.data(), sizeof(cpx) * pts))) return e;
+  if (p->g.logb > kLdsMaxLog) {
+    int l1, l2, llo;
+    fourstep_split(p->g.logb, &l1, &l2, &llo);
+    const int n = pts, n1 = 1 << l1, n2 = 1 << l2, lo = 1 << llo, hi = n >> llo;
+    std::vector<cpx> all, part;
+    fill_twiddle(part, n1 / 2, n1, 1, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + n1 / 2);
+    fill_twiddle(part, n2 / 2, n2, 1, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + n2 / 2);
+    fill_twiddle(part, lo, n, 1, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + lo);
+    fill_twiddle(part, hi, n, lo, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + hi);
+    if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
+    p->big.four = (const cpx *)p->four.p;
+    if ((e = p->scratch.ensure((size_t)fourstep_grid(p->g.logb, 0, p->di) * n * sizeof(cpx)))) return e;
+    if ((e = p->work.ensure(sizeof(cpx) * (size_t)channels * n))) return e;
+  }
   const size_t ring = sizeof(cpx) * (size_t)channels * p->g.nparts * pts;
   const size_t blk = sizeof(float) * (size_t)channels * pts;
   if ((e = p->ringA.ensure(ring))) return e;
   if ((e = p->ringB.ensure(ring))) return e;
-  if ((e = p->acc.ensure(sizeof(cpx) * (size_t)channels * pts))) return e;
+  if ((e = p->acc.ensure(sizeof(cpx) * (size_t)channels * pts * pconv_mac_split(p->g)))) return e;
   if ((e = p->tail.ensure(blk))) return e;
   // zero-initialised state (cl_conv.cpp:303-313)
   HIP_TRY(hipMemsetAsync(p->ringA.p, 0, ring, p->stream));
@@ -517,7 +537,7 @@ void clfa_pconv_destroy(clfa_pconv *p) {
     (void)hipStreamDestroy(p->stream);
   }
   for (DevBuf *b : {&p->half, &p->w2f, &p->w2i, &p->ringA, &p->ringB, &p->acc, &p->tail, &p->in1, &p->in2,
-                    &p->out, &p->ir})
+                    &p->out, &p->ir, &p->four, &p->scratch, &p->work})
     b->release();
   delete p;
 }
@@ -530,6 +550,38 @@ size_t clfa_pconv_state_bytes(const clfa_pconv *p) {
   return p ? p->ringA.bytes + p->ringB.bytes + p->acc.bytes + p->tail.bytes : 0;
 }
 
+// forward chain of one block for all channels: in -> spectrum frame `frame` of `ring`
+static int pconv_forward(clfa_pconv *p, const float *in, long in_stride, cpx *ring, int frame, hipStream_t s) {
+  if (p->g.logb <= kLdsMaxLog) {
+    HIP_TRY(launch_pconv_forward(p->g, in, in_stride, ring, frame, (const cpx *)p->half.p, (const cpx *)p->w2f.p, s));
+    return CLFA_SUCCESS;
+  }
+  // composed: zero-pad -> large-N forward FFT (unscaled) -> reference r2c -> place the frames in the ring
+  const int bins = p->g.bins, ch = p->g.channels;
+  cpx *work = (cpx *)p->work.p;
+  HIP_TRY(launch_pconv_pad(in, in_stride, work, bins, ch, s));
+  HIP_TRY(launch_fft_4step(p->g.logb, true, false, 0, work, (cpx *)p->scratch.p, p->big, ch, p->di, s));
+  HIP_TRY(launch_r2c_pack(work, (const cpx *)p->w2f.p, bins, ch, s));
+  HIP_TRY(hipMemcpy2DAsync(ring + (size_t)frame * bins, sizeof(cpx) * (size_t)p->g.nparts * bins, work,
+                           sizeof(cpx) * (size_t)bins, sizeof(cpx) * (size_t)bins, ch, hipMemcpyDeviceToDevice, s));
+  return CLFA_SUCCESS;
+}
+
+// inverse chain: accumulator -> c2r -> inverse FFT -> overlap-add
+static int pconv_inverse(clfa_pconv *p, float *out, hipStream_t s) {
+  if (p->g.logb <= kLdsMaxLog) {
+    HIP_TRY(launch_pconv_inverse(p->g, (const cpx *)p->acc.p, (float *)p->tail.p, out, (const cpx *)p->half.p,
+                                 (const cpx *)p->w2i.p, s));
+    return CLFA_SUCCESS;
+  }
+  const int bins = p->g.bins, ch = p->g.channels;
+  cpx *acc = (cpx *)p->acc.p;
+  HIP_TRY(launch_c2r_unpack(acc, (const cpx *)p->w2i.p, bins, ch, s));
+  HIP_TRY(launch_fft_4step(p->g.logb, false, false, 0, acc, (cpx *)p->scratch.p, p->big, ch, p->di, s));
+  HIP_TRY(launch_pconv_olap((const float *)acc, (float *)p->tail.p, out, bins, ch, s));
+  return CLFA_SUCCESS;
+}
+
 int clfa_pconv_push_ir_dev(clfa_pconv *p, const void *ir, void *stream) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
@@ -539,8 +591,8 @@ int clfa_pconv_push_ir_dev(clfa_pconv *p, const void *ir, void *stream) {
   const long stride = (long)p->g.nparts * p->pts;
   // cl_conv.cpp:358-386: partition i -> frame wp2, wp2 counts down from nparts-1
   for (int i = 0; i < p->g.nparts; i++) {
-    HIP_TRY(launch_pconv_forward(p->g, (const float *)ir + (long)i * p->pts, stride, (cpx *)p->ringB.p, p->wp2,
-                                 (const cpx *)p->half.p, (const cpx *)p->w2f.p, s));
+    int e = pconv_forward(p, (const float *)ir + (long)i * p->pts, stride, (cpx *)p->ringB.p, p->wp2, s);
+    if (e) return e;
     p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;
   }
   return CLFA_SUCCESS;
@@ -566,19 +618,15 @@ int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void
   if (!out || !in1) return CLFA_INVALID_VALUE;
   HIP_TRY(hipSetDevice(p->di.device));
   hipStream_t s = (hipStream_t)stream;
-  const cpx *half = (const cpx *)p->half.p;
+  int e;
   // forward chain(s): cl_conv.cpp:399-419 / 465-513
-  HIP_TRY(launch_pconv_forward(p->g, (const float *)in1, p->pts, (cpx *)p->ringA.p, p->wp, half,
-                               (const cpx *)p->w2f.p, s));
-  if (in2)
-    HIP_TRY(launch_pconv_forward(p->g, (const float *)in2, p->pts, (cpx *)p->ringB.p, p->wp2, half,
-                                 (const cpx *)p->w2f.p, s));
+  if ((e = pconv_forward(p, (const float *)in1, p->pts, (cpx *)p->ringA.p, p->wp, s))) return e;
+  if (in2 && (e = pconv_forward(p, (const float *)in2, p->pts, (cpx *)p->ringB.p, p->wp2, s))) return e;
   p->wp = p->wp != p->g.nparts - 1 ? p->wp + 1 : 0;            // cl_conv.cpp:424 / 516
   if (in2) p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;  // cl_conv.cpp:519
   // cl_conv.cpp:428-449
   HIP_TRY(launch_pconv_mac(p->g, (const cpx *)p->ringA.p, (const cpx *)p->ringB.p, p->wp, (cpx *)p->acc.p, s));
-  HIP_TRY(launch_pconv_inverse(p->g, (const cpx *)p->acc.p, (float *)p->tail.p, (float *)out, half,
-                               (const cpx *)p->w2i.p, s));
+  if ((e = pconv_inverse(p, (float *)out, s))) return e;
   return CLFA_SUCCESS;
 }
 

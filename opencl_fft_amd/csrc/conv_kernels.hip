@@ -100,21 +100,27 @@ struct alignas(16) cpx2 {
   cpx a, b;
 };
 
-// one lane = two adjacent bins (16 B) of one channel; loops the partitions
+// one lane = two adjacent bins (16 B) of one channel; loops the partitions of its segment.
+// blockIdx.y = segment of the partition axis (1 segment when there are enough channels to fill
+// the chip; few channels with long filters are split and summed by k_pconv_reduce in fixed order)
 template <int UNROLL>
 __global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, const cpx *__restrict__ B,
                                                    cpx *__restrict__ acc, int wp, int bins, int nparts,
-                                                   long total /* channels * bins/2 */) {
+                                                   long total /* channels * bins/2 */, int chunk) {
   const int hb = bins >> 1;
+  const int p_begin = blockIdx.y * chunk;
+  const int p_end = p_begin + chunk < nparts ? p_begin + chunk : nparts;
+  cpx *dst = acc + (long)blockIdx.y * total * 2;
   for (long g = blockIdx.x * 256L + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
     const long ch = g / hb;
     const int i2 = (int)(g % hb);
     const cpx2 *a = reinterpret_cast<const cpx2 *>(A + ch * (long)nparts * bins) + i2;
     const cpx2 *b = reinterpret_cast<const cpx2 *>(B + ch * (long)nparts * bins) + i2;
     cpx s0 = mk(0.f, 0.f), s1 = mk(0.f, 0.f);
-    int fr = wp;  // ring frame of partition p = 0 (the oldest input block)
-    int p = 0;
-    for (; p + UNROLL <= nparts; p += UNROLL) {
+    int fr = wp + p_begin;  // ring frame of partition p_begin (wp = frame of the oldest input block)
+    fr = fr < nparts ? fr : fr - nparts;
+    int p = p_begin;
+    for (; p + UNROLL <= p_end; p += UNROLL) {
       cpx2 av[UNROLL], bv[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) {
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, co
       fr += UNROLL;
       fr = fr < nparts ? fr : fr - nparts;
     }
-    for (; p < nparts; p++) {
+    for (; p < p_end; p++) {
       cpx2 av = a[(long)fr * hb], bv = b[(long)p * hb];
       if (i2 == 0) {
         s0.x += av.a.x * bv.a.x;
@@ -150,8 +156,26 @@ __global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, co
     cpx2 o;
     o.a = s0;
     o.b = s1;
-    reinterpret_cast<cpx2 *>(acc + ch * (long)bins)[i2] = o;
+    reinterpret_cast<cpx2 *>(dst)[g] = o;
   }
+}
+
+// acc[0] += acc[1] + ... + acc[nsplit-1], ascending (deterministic)
+__global__ __launch_bounds__(256) void k_pconv_reduce(cpx *__restrict__ acc, long total2, int nsplit) {
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < total2; g += (long)gridDim.x * 256) {
+    cpx s = acc[g];
+    for (int k = 1; k < nsplit; k++) s = cadd(s, acc[(long)k * total2 + g]);
+    acc[g] = s;
+  }
+}
+
+int pconv_mac_split(const PconvGeom &g) {
+  // split only when channels x bins/2 gives fewer than ~64K lanes (config 4 has 131072: no split)
+  long lanes = (long)g.channels * (g.bins / 2);
+  long want = (64L * 1024 + lanes - 1) / lanes;
+  if (want > 64) want = 64;
+  if (want > g.nparts / 4) want = g.nparts / 4;
+  return want < 1 ? 1 : (int)want;
 }
 
 hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp, cpx *acc,
@@ -159,8 +183,15 @@ hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *rin
   long total = (long)g.channels * (g.bins / 2);
   long grid = (total + 255) / 256;
   if (grid > 256 * 64) grid = 256 * 64;
-  hipLaunchKernelGGL((k_pconv_mac<4>), dim3((int)grid), dim3(256), 0, s, ringA, ringB, acc, wp, g.bins,
-                     g.nparts, total);
+  const int nsplit = pconv_mac_split(g);
+  const int chunk = (g.nparts + nsplit - 1) / nsplit;
+  hipLaunchKernelGGL((k_pconv_mac<4>), dim3((int)grid, nsplit), dim3(256), 0, s, ringA, ringB, acc, wp, g.bins,
+                     g.nparts, total, chunk);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || nsplit == 1) return e;
+  long total2 = total * 2, rgrid = (total2 + 255) / 256;
+  if (rgrid > 4096) rgrid = 4096;
+  hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid), dim3(256), 0, s, acc, total2, nsplit);
   return hipGetLastError();
 }
 
@@ -248,6 +279,44 @@ hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail,
     default:
       return hipErrorInvalidValue;
   }
+}
+
+// ---------------------------------------------------------------------------------
+// partitions above the LDS sizes (pts = 16384, 32768): the same chain composed from the
+// large-N FFT kernel; these two kernels are its zero-padding and overlap-add ends
+// ---------------------------------------------------------------------------------
+// work[ch][p] = p < bins/2 ? (in[ch][2p], in[ch][2p+1]) : 0   (cl_conv.cpp:399: half of in1 is written)
+__global__ __launch_bounds__(256) void k_pconv_pad(const float *__restrict__ in, long in_stride,
+                                                   cpx *__restrict__ work, int bins, long total) {
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long ch = g / bins;
+    const int p = (int)(g % bins);
+    work[g] = p < bins / 2 ? reinterpret_cast<const cpx *>(in + ch * in_stride)[p] : mk(0.f, 0.f);
+  }
+}
+// reference olap (cl_conv_kernels.h:120-124) on work viewed as 2*bins floats per channel
+__global__ __launch_bounds__(256) void k_pconv_olap(const float *__restrict__ work, float *__restrict__ tail,
+                                                    float *__restrict__ out, int bins, long total) {
+  const float inv = 1.0f / (float)bins;
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long ch = g / bins;
+    const int n = (int)(g % bins);
+    const float *t = work + ch * 2L * bins;
+    out[g] = (t[n] + tail[g]) * inv;
+    tail[g] = t[bins + n];
+  }
+}
+hipError_t launch_pconv_pad(const float *in, long in_stride, cpx *work, int bins, int channels, hipStream_t s) {
+  long total = (long)channels * bins, grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_pconv_pad, dim3((int)grid), dim3(256), 0, s, in, in_stride, work, bins, total);
+  return hipGetLastError();
+}
+hipError_t launch_pconv_olap(const float *work, float *tail, float *out, int bins, int channels, hipStream_t s) {
+  long total = (long)channels * bins, grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_pconv_olap, dim3((int)grid), dim3(256), 0, s, work, tail, out, bins, total);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------

@@ -65,6 +65,7 @@ struct PconvGeom {
 hipError_t launch_pconv_forward(const PconvGeom &g, const float *in, long in_stride, cpx *ring, int frame,
                                 const cpx *half, const cpx *w2f, hipStream_t s);
 // acc = sum_p A[(wp+p)%nparts] (.) B[p]  (cl_conv_kernels.h:102-118), acc: channels x bins complex
+int pconv_mac_split(const PconvGeom &g);   // partial accumulators the MAC writes (acc must hold that many)
 hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp, cpx *acc,
                             hipStream_t s);
 // acc -> c2r -> inverse FFT -> overlap-add (cl_conv_kernels.h:87-100,120-124); out channels x pts,
@@ -74,7 +75,10 @@ hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail,
 // fused: MAC + inverse in one kernel (one workgroup per channel)
 hipError_t launch_pconv_mac_inverse(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp,
                                     float *tail, float *out, const cpx *half, const cpx *w2i, hipStream_t s);
-constexpr int kPconvMaxLogBins = 13;
+constexpr int kPconvMaxLogBins = 15;   // pts up to 32768 (the reference harness' largest, csound/tests.py:13)
+// ends of the composed chain used when bins exceed the LDS FFT sizes
+hipError_t launch_pconv_pad(const float *in, long in_stride, cpx *work, int bins, int channels, hipStream_t s);
+hipError_t launch_pconv_olap(const float *work, float *tail, float *out, int bins, int channels, hipStream_t s);
 
 // ---- direct convolution ----------------------------------------------------------
 hipError_t launch_dconv(float *out, const float *del, const float *coefs, int irsize, int vsize, int rp,

@@ -62,7 +62,8 @@ def test_pconv_ring_indices_bit_exact():
 
 
 @pytest.mark.parametrize("pts,nparts,channels,blocks", [(2, 1, 3, 4), (16, 5, 7, 12), (256, 3, 5, 8), (1024, 6, 3, 9),
-                                                        (4096, 2, 2, 5), (8192, 2, 1, 4)])
+                                                        (4096, 2, 2, 5), (8192, 2, 1, 4), (16384, 2, 2, 4),
+                                                        (32768, 3, 1, 5)])
 def test_pconv_multichannel_vs_oracle(pts, nparts, channels, blocks):
     """`channels` independent instances in one object == that many oracle objects"""
     s = util.lcg_half(7 + pts, channels * (pts * nparts + pts * blocks))
