@@ -242,13 +242,11 @@ template <int LOGN> struct FourGeom {
 
 // phase 1 of one slice: column block cb of `src` (N1 x N2, row-major) ->
 // N1-point FFT down the columns, times W_N^(n2*k1), stored to dst[k1][n2].
-template <int LOGN, bool FWD, bool NT>
-__device__ __forceinline__ void four_phase1(const cpx *__restrict__ src, cpx *__restrict__ dst, int cb, int l,
-                                            const cpx *tab1, const cpx *tlo, const cpx *thi, cpx *sx) {
+template <int LOGN, bool NT>
+__device__ __forceinline__ void four_load1(cpx (&v)[16], const cpx *__restrict__ src, int cb, int l) {
   using G = FourGeom<LOGN>;
   const int col = l % G::C1, tf = l / G::C1;
   const int n2 = cb * G::C1 + col;
-  cpx v[16];
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const cpx *p = src + (long)(tf + G::T1 * e) * G::N2 + n2;
@@ -259,6 +257,13 @@ __device__ __forceinline__ void four_phase1(const cpx *__restrict__ src, cpx *__
       v[e] = *p;
     }
   }
+}
+template <int LOGN, bool FWD>
+__device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, int cb, int l, const cpx *tab1,
+                                           const cpx *tlo, const cpx *thi, cpx *sx) {
+  using G = FourGeom<LOGN>;
+  const int col = l % G::C1, tf = l / G::C1;
+  const int n2 = cb * G::C1 + col;
   pass_compute<G::LOGN1, 4, 0, FWD>(v, tf, tab1);
   __syncthreads();
   pass_scatter<G::LOGN1, 4, 0>(v, tf, [&](int p, cpx val) { sx[p * G::C1 + col] = val; });
@@ -274,9 +279,14 @@ __device__ __forceinline__ void four_phase1(const cpx *__restrict__ src, cpx *__
     dst[(long)k1 * G::N2 + n2] = cmul(v[e], w);
   }
 }
+template <int LOGN, bool FWD, bool NT>
+__device__ __forceinline__ void four_phase1(const cpx *__restrict__ src, cpx *__restrict__ dst, int cb, int l,
+                                            const cpx *tab1, const cpx *tlo, const cpx *thi, cpx *sx) {
+  cpx v[16];
+  four_load1<LOGN, NT>(v, src, cb, l);
+  four_body1<LOGN, FWD>(v, dst, cb, l, tab1, tlo, thi, sx);
+}
 
-// phase 2 of one slice: row block rb of `src` (rows k1, contiguous n2) ->
-// N2-point FFT along each row -> dst[k1 + N1*k2] (natural order of the result)
 // 8-byte load that bypasses the CU's vector L1 (global_load_dwordx2 ... sc1): data another
 // CU of the same XCD has stored is served from the shared L2 (MI355X_MICROARCH.md, workgroup
 // dispatch & inter-workgroup visibility)
@@ -286,22 +296,26 @@ __device__ __forceinline__ cpx ld_sc1(const cpx *p) {
   return *reinterpret_cast<cpx *>(&raw);
 }
 
-template <int LOGN, bool FWD, bool SCALE, bool NT, bool SC1 = false>
-__device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__restrict__ dst, int rb, int l,
-                                            const cpx *tab2, cpx *sx, unsigned *read_done = nullptr) {
+template <int LOGN, bool SC1>
+__device__ __forceinline__ void four_load2(cpx (&v)[16], const cpx *__restrict__ src, int rb, int l) {
   using G = FourGeom<LOGN>;
-  cpx v[16];
+  const int tf = l % G::T2, row = l / G::T2;
+  const cpx *p = src + (long)(rb * G::R2 + row) * G::N2 + tf;
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = SC1 ? ld_sc1(p + G::T2 * e) : p[G::T2 * e];
+}
+template <int LOGN, bool FWD, bool SCALE, bool NT>
+__device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, int rb, int l, const cpx *tab2,
+                                           cpx *sx, unsigned *read_done = nullptr) {
+  using G = FourGeom<LOGN>;
   {
     const int tf = l % G::T2, row = l / G::T2;
-    const cpx *p = src + (long)(rb * G::R2 + row) * G::N2 + tf;
-#pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = SC1 ? ld_sc1(p + G::T2 * e) : p[G::T2 * e];
     pass_compute<G::LOGN2, 4, 0, FWD>(v, tf, tab2);
     __syncthreads();
     cpx *xr = sx + row * G::S2;
     pass_scatter<G::LOGN2, 4, 0>(v, tf, [&](int q, cpx val) { xr[lds_pad(q)] = val; });
     __syncthreads();
-    // every lane has consumed its loads from `src`: the scratch slot may be reused
+    // every lane has consumed its loads from the scratch: the slot may be reused
     if (read_done != nullptr && l == 0)
       (void)__hip_atomic_fetch_add(read_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // in the XCD's L2
   }
@@ -326,8 +340,17 @@ __device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__
     }
   }
 }
+// phase 2 of one slice: row block rb of `src` (rows k1, contiguous n2) ->
+// N2-point FFT along each row -> dst[k1 + N1*k2] (natural order of the result)
+template <int LOGN, bool FWD, bool SCALE, bool NT, bool SC1 = false>
+__device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__restrict__ dst, int rb, int l,
+                                            const cpx *tab2, cpx *sx, unsigned *read_done = nullptr) {
+  cpx v[16];
+  four_load2<LOGN, SC1>(v, src, rb, l);
+  four_body2<LOGN, FWD, SCALE, NT>(v, dst, rb, l, tab2, sx, read_done);
+}
 
-template <int LOGN, bool FWD, bool SCALE, int NSLICE, bool NT>
+template <int LOGN, bool FWD, bool SCALE, int NSLICE, bool NT, bool PF = false>
 __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ data, cpx *__restrict__ scratch,
                                                            const cpx *__restrict__ tabs_g, long batch) {
   using G = FourGeom<LOGN>;
@@ -344,13 +367,46 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
 #pragma unroll 1
   for (long b = blockIdx.x; b < batch; b += gridDim.x) {
     cpx *x = data + b * (long)G::N;
+    if constexpr (!PF) {
 #pragma unroll 1
-    for (int cb = slice; cb < G::NCB; cb += NSLICE) four_phase1<LOGN, FWD, NT>(x, mid, cb, l, tab1, tlo, thi, sx);
-    // the workgroup re-reads what it has just stored: workgroup-scope release/acquire
-    __syncthreads();
+      for (int cb = slice; cb < G::NCB; cb += NSLICE) four_phase1<LOGN, FWD, NT>(x, mid, cb, l, tab1, tlo, thi, sx);
+      // the workgroup re-reads what it has just stored: workgroup-scope release/acquire
+      __syncthreads();
 #pragma unroll 1
-    for (int rb = slice; rb < G::NRB; rb += NSLICE) four_phase2<LOGN, FWD, SCALE, NT>(mid, x, rb, l, tab2, sx);
-    __syncthreads();
+      for (int rb = slice; rb < G::NRB; rb += NSLICE) four_phase2<LOGN, FWD, SCALE, NT>(mid, x, rb, l, tab2, sx);
+      __syncthreads();
+    } else {
+      // software-prefetched form: the next block's loads fly behind the current block's passes.
+      // The last block of each phase is peeled so that every prefetch is straight-line code
+      // (counted s_waitcnt, see k_fft_lds), and consumed at the end of the iteration.
+      cpx v[16], vn[16];
+      four_load1<LOGN, NT>(v, x, slice, l);
+#pragma unroll 1
+      for (int cb = slice; cb + NSLICE < G::NCB; cb += NSLICE) {
+        four_load1<LOGN, NT>(vn, x, cb + NSLICE, l);
+        four_body1<LOGN, FWD>(v, mid, cb, l, tab1, tlo, thi, sx);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
+          v[e] = vn[e];
+        }
+      }
+      four_body1<LOGN, FWD>(v, mid, G::NCB - NSLICE + slice, l, tab1, tlo, thi, sx);
+      __syncthreads();
+      four_load2<LOGN, false>(v, mid, slice, l);
+#pragma unroll 1
+      for (int rb = slice; rb + NSLICE < G::NRB; rb += NSLICE) {
+        four_load2<LOGN, false>(vn, mid, rb + NSLICE, l);
+        four_body2<LOGN, FWD, SCALE, NT>(v, x, rb, l, tab2, sx);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
+          v[e] = vn[e];
+        }
+      }
+      four_body2<LOGN, FWD, SCALE, NT>(v, x, G::NRB - NSLICE + slice, l, tab2, sx);
+      __syncthreads();
+    }
   }
 }
 
@@ -358,18 +414,25 @@ struct FourVariant {
   int nslice;
   bool nt;
   int wg_per_cu;
+  bool pf;   // software prefetch of the next column / row block
 };
 static FourVariant four_variant(int variant) {
   // {slices of 256 lanes per workgroup, non-temporal streaming, workgroups per CU}.
   // Measured on MI355X, N = 65536 x 4096 (profiles/): 0 is the fastest (1.45 ms).
   switch (variant) {
-    case 1: return {4, false, 1};
-    case 2: return {2, false, 2};
-    case 3: return {4, true, 1};
-    case 4: return {1, false, 4};
-    case 5: return {1, false, 2};
-    case 6: return {2, false, 1};
-    default: return {2, true, 2};  // 0
+    case 1: return {4, false, 1, false};
+    case 2: return {2, false, 2, false};
+    case 3: return {4, true, 1, false};
+    case 4: return {1, false, 4, false};
+    case 5: return {1, false, 2, false};
+    case 6: return {2, false, 1, false};
+    case 8: return {1, true, 4, false};
+    case 9: return {2, true, 2, false};
+    case 10: return {1, true, 2, false};
+    case 11: return {1, true, 2, true};
+    case 12: return {2, true, 1, true};
+    case 13: return {2, true, 2, true};
+    default: return {1, true, 2, false};  // 0
   }
 }
 
@@ -390,13 +453,14 @@ static hipError_t launch_4step_v(int variant, cpx *data, cpx *scratch, const Fft
   FourVariant v = four_variant(variant);
   int grid = fourstep_grid(LOGN, variant, di);
   if (batch < grid) grid = (int)batch;
-#define CLFA_V(NS, NT)                                                                                    \
-  if (v.nslice == NS && v.nt == NT) {                                                                     \
-    hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE, NS, NT>), dim3(grid), dim3(256 * NS), 0, s, data,   \
-                       scratch, t.four, batch);                                                           \
-    return hipGetLastError();                                                                             \
+#define CLFA_V(NS, NT, PF)                                                                                  \
+  if (v.nslice == NS && v.nt == NT && v.pf == PF) {                                                         \
+    hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE, NS, NT, PF>), dim3(grid), dim3(256 * NS), 0, s, data, \
+                       scratch, t.four, batch);                                                             \
+    return hipGetLastError();                                                                               \
   }
-  CLFA_V(4, true) CLFA_V(4, false) CLFA_V(2, false) CLFA_V(2, true) CLFA_V(1, false)
+  CLFA_V(4, true, false) CLFA_V(4, false, false) CLFA_V(2, false, false) CLFA_V(2, true, false)
+  CLFA_V(1, false, false) CLFA_V(1, true, false) CLFA_V(1, true, true) CLFA_V(2, true, true)
 #undef CLFA_V
   return hipErrorInvalidValue;
 }

@@ -20,7 +20,7 @@ def main():
     src = d.clone()
     ms = timeit(lambda: d.copy_(src))
     print("copy 2GiB->2GiB: %.3f ms = %.2f TB/s (r+w)" % (ms, 2 * d.numel() * 4 / ms / 1e9))
-    for variant in [int(a) for a in sys.argv[1:]] or [0, 7]:
+    for variant in [int(a) for a in sys.argv[1:]] or [0]:
         plan = fa.Clcfft(0, n, True)
         assert plan.set_variant(variant) == 0
         d.copy_(src)
