@@ -296,7 +296,7 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     size_t sbytes = (size_t)fourstep_grid(p->logn, p->variant, p->di) * n * sizeof(cpx);
     if (p->variant == kVariantCoop) sbytes = coop_scratch_bytes(p->logn);
     if ((e = p->scratch.ensure(sbytes))) return e;
-    if ((e = p->ctl.ensure(coop_ctl_bytes()))) return e;
+    if ((e = p->ctl.ensure(coop_ctl_bytes() > coop2_ctl_bytes() ? coop_ctl_bytes() : coop2_ctl_bytes()))) return e;
   }
   if (real) {
     fill_w2(h, n, fwd ? -1.f : 1.f);
@@ -356,14 +356,14 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
 }
 
 int clfa_fft_set_variant(clfa_fft *p, int variant) {
-  if (!p || variant < 0 || variant > 13) return CLFA_INVALID_VALUE;
+  if (!p || variant < 0 || variant > kVariantCoop2) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   p->variant = variant;
   if (p->logn > kLdsMaxLog) {
     HIP_TRY(hipSetDevice(p->di.device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     size_t sbytes = (size_t)fourstep_grid(p->logn, variant, p->di) * p->n * sizeof(cpx);
-    if (variant == kVariantCoop) sbytes = coop_scratch_bytes(p->logn);
+    if (variant == kVariantCoop || variant == kVariantCoop2) sbytes = coop_scratch_bytes(p->logn);
     int e = p->scratch.ensure(sbytes);
     if (e) return e;
   }
@@ -377,6 +377,7 @@ int clfa_fft_sync_check(clfa_fft *p, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   unsigned err = 0;
   if (p->logn > kLdsMaxLog && p->variant == kVariantCoop && p->ctl.p) HIP_TRY(coop_read_error(p->ctl.p, &err, s));
+  if (p->logn > kLdsMaxLog && p->variant == kVariantCoop2 && p->ctl.p) HIP_TRY(coop2_read_error(p->ctl.p, &err, s));
   HIP_TRY(hipStreamSynchronize(s));
   return err ? CLFA_OUT_OF_RESOURCES : CLFA_SUCCESS;
 }
@@ -398,6 +399,8 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   if (p->real && !p->fwd) HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, p->n, batch, s));
   if (p->variant == kVariantCoop)
     HIP_TRY(launch_fft_coop(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));
+  else if (p->variant == kVariantCoop2)
+    HIP_TRY(launch_fft_coop2(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));
   else
     HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, p->variant, d, (cpx *)p->scratch.p, p->tabs, batch, p->di, s));
   if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, p->n, batch, s));

@@ -242,7 +242,8 @@ template <int LOGN> struct FourGeom {
 
 // phase 1 of one slice: column block cb of `src` (N1 x N2, row-major) ->
 // N1-point FFT down the columns, times W_N^(n2*k1), stored to dst[k1][n2].
-template <int LOGN, bool NT>
+// streaming mode of the input loads / output stores: 0 plain, 1 non-temporal, 2 system scope (sc0 sc1)
+template <int LOGN, int SM>
 __device__ __forceinline__ void four_load1(cpx (&v)[16], const cpx *__restrict__ src, int cb, int l) {
   using G = FourGeom<LOGN>;
   const int col = l % G::C1, tf = l / G::C1;
@@ -250,8 +251,12 @@ __device__ __forceinline__ void four_load1(cpx (&v)[16], const cpx *__restrict__
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const cpx *p = src + (long)(tf + G::T1 * e) * G::N2 + n2;
-    if constexpr (NT) {
+    if constexpr (SM == 1) {
       const unsigned long long raw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
+      v[e] = *reinterpret_cast<const cpx *>(&raw);
+    } else if constexpr (SM == 2) {
+      const unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       v[e] = *reinterpret_cast<const cpx *>(&raw);
     } else {
       v[e] = *p;
@@ -279,11 +284,11 @@ __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, 
     dst[(long)k1 * G::N2 + n2] = cmul(v[e], w);
   }
 }
-template <int LOGN, bool FWD, bool NT>
+template <int LOGN, bool FWD, int SM>
 __device__ __forceinline__ void four_phase1(const cpx *__restrict__ src, cpx *__restrict__ dst, int cb, int l,
                                             const cpx *tab1, const cpx *tlo, const cpx *thi, cpx *sx) {
   cpx v[16];
-  four_load1<LOGN, NT>(v, src, cb, l);
+  four_load1<LOGN, SM>(v, src, cb, l);
   four_body1<LOGN, FWD>(v, dst, cb, l, tab1, tlo, thi, sx);
 }
 
@@ -304,7 +309,7 @@ __device__ __forceinline__ void four_load2(cpx (&v)[16], const cpx *__restrict__
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = SC1 ? ld_sc1(p + G::T2 * e) : p[G::T2 * e];
 }
-template <int LOGN, bool FWD, bool SCALE, bool NT>
+template <int LOGN, bool FWD, bool SCALE, int SM>
 __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, int rb, int l, const cpx *tab2,
                                            cpx *sx, unsigned *read_done = nullptr) {
   using G = FourGeom<LOGN>;
@@ -332,9 +337,12 @@ __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, 
     cpx o = v[e];
     if constexpr (SCALE) o = cscale(o, 1.0f / (float)G::N);
     cpx *p = dst + (long)k2 * G::N1 + k1;
-    if constexpr (NT) {
+    if constexpr (SM == 1) {
       __builtin_nontemporal_store(*reinterpret_cast<unsigned long long *>(&o),
                                   reinterpret_cast<unsigned long long *>(p));
+    } else if constexpr (SM == 2) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), *reinterpret_cast<unsigned long long *>(&o),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
       *p = o;
     }
@@ -342,12 +350,12 @@ __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, 
 }
 // phase 2 of one slice: row block rb of `src` (rows k1, contiguous n2) ->
 // N2-point FFT along each row -> dst[k1 + N1*k2] (natural order of the result)
-template <int LOGN, bool FWD, bool SCALE, bool NT, bool SC1 = false>
+template <int LOGN, bool FWD, bool SCALE, int SM, bool SC1 = false>
 __device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__restrict__ dst, int rb, int l,
                                             const cpx *tab2, cpx *sx, unsigned *read_done = nullptr) {
   cpx v[16];
   four_load2<LOGN, SC1>(v, src, rb, l);
-  four_body2<LOGN, FWD, SCALE, NT>(v, dst, rb, l, tab2, sx, read_done);
+  four_body2<LOGN, FWD, SCALE, SM>(v, dst, rb, l, tab2, sx, read_done);
 }
 
 template <int LOGN, bool FWD, bool SCALE, int NSLICE, bool NT, bool PF = false>
@@ -369,21 +377,21 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
     cpx *x = data + b * (long)G::N;
     if constexpr (!PF) {
 #pragma unroll 1
-      for (int cb = slice; cb < G::NCB; cb += NSLICE) four_phase1<LOGN, FWD, NT>(x, mid, cb, l, tab1, tlo, thi, sx);
+      for (int cb = slice; cb < G::NCB; cb += NSLICE) four_phase1<LOGN, FWD, NT ? 1 : 0>(x, mid, cb, l, tab1, tlo, thi, sx);
       // the workgroup re-reads what it has just stored: workgroup-scope release/acquire
       __syncthreads();
 #pragma unroll 1
-      for (int rb = slice; rb < G::NRB; rb += NSLICE) four_phase2<LOGN, FWD, SCALE, NT>(mid, x, rb, l, tab2, sx);
+      for (int rb = slice; rb < G::NRB; rb += NSLICE) four_phase2<LOGN, FWD, SCALE, NT ? 1 : 0>(mid, x, rb, l, tab2, sx);
       __syncthreads();
     } else {
       // software-prefetched form: the next block's loads fly behind the current block's passes.
       // The last block of each phase is peeled so that every prefetch is straight-line code
       // (counted s_waitcnt, see k_fft_lds), and consumed at the end of the iteration.
       cpx v[16], vn[16];
-      four_load1<LOGN, NT>(v, x, slice, l);
+      four_load1<LOGN, NT ? 1 : 0>(v, x, slice, l);
 #pragma unroll 1
       for (int cb = slice; cb + NSLICE < G::NCB; cb += NSLICE) {
-        four_load1<LOGN, NT>(vn, x, cb + NSLICE, l);
+        four_load1<LOGN, NT ? 1 : 0>(vn, x, cb + NSLICE, l);
         four_body1<LOGN, FWD>(v, mid, cb, l, tab1, tlo, thi, sx);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
@@ -397,14 +405,14 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
 #pragma unroll 1
       for (int rb = slice; rb + NSLICE < G::NRB; rb += NSLICE) {
         four_load2<LOGN, false>(vn, mid, rb + NSLICE, l);
-        four_body2<LOGN, FWD, SCALE, NT>(v, x, rb, l, tab2, sx);
+        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, rb, l, tab2, sx);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
           v[e] = vn[e];
         }
       }
-      four_body2<LOGN, FWD, SCALE, NT>(v, x, G::NRB - NSLICE + slice, l, tab2, sx);
+      four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, G::NRB - NSLICE + slice, l, tab2, sx);
       __syncthreads();
     }
   }
@@ -578,7 +586,7 @@ __device__ __forceinline__ CoopSlot coop_load_slot(CoopSlot *r) {
   return v;
 }
 
-template <int LOGN, bool FWD, bool SCALE>
+template <int LOGN, bool FWD, bool SCALE, int SM = 1>
 __global__ __launch_bounds__(256, 3) void k_fft_coop(cpx *__restrict__ data, cpx *__restrict__ scratch,
                                                      const cpx *__restrict__ tabs_g, long batch, CoopCtl *ctl,
                                                      int nslots, int lag) {
@@ -691,12 +699,225 @@ __global__ __launch_bounds__(256, 3) void k_fft_coop(cpx *__restrict__ data, cpx
     cpx *x = data + (long)(xf - 1) * G::N;
     cpx *mid = sbase + (long)(i % nslots) * G::N;
     if (p1) {
-      four_phase1<LOGN, FWD, true>(x, mid, (int)idx, tid, tab1, tlo, thi, s_x);
+      four_phase1<LOGN, FWD, SM>(x, mid, (int)idx, tid, tab1, tlo, thi, s_x);
       if (tid == 0) pend = &rec->c1;  // signalled once every wave has drained its stores
     } else {
-      four_phase2<LOGN, FWD, SCALE, true, true>(mid, x, (int)idx, tid, tab2, s_x, &rec->c2);
+      four_phase2<LOGN, FWD, SCALE, SM, true>(mid, x, (int)idx, tid, tab2, s_x, &rec->c2);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// readiness-driven cooperative kernel (variant 14)
+// ---------------------------------------------------------------------------------
+// Same per-XCD structures as k_fft_coop, different scheduling: instead of one queue in a
+// fixed order, each XCD keeps
+//   p1_claim   phase-1 tasks claimed so far (transform = claim / TPG, column block = claim % TPG)
+//   ready[]    local transforms whose phase 1 is complete, in completion order (ready_tail entries)
+//   p2_claim   phase-2 tasks claimed so far (entry = claim / TPG of the ready list)
+// A workgroup first tries to claim a phase-2 task (only if one is READY: compare-and-swap on
+// p2_claim against ready_tail), else a phase-1 task (only if the slot of that transform is FREE),
+// else sleeps and retries.  A claimed task never waits for anything but short publication
+// windows of another running workgroup, so no workgroup ever holds a ticket it cannot run:
+// no deadlock for any grid size, residency or placement.  With S slots the steady state is
+// S/2 transforms in phase 1 and S/2 in phase 2 per XCD; live scratch = S x n x 8 bytes.
+constexpr int kCoopReadyRing = 64;
+struct alignas(256) Coop2Xcd {
+  CoopWord p1_claim, p2_claim, ready_tail, draws, endinv, p2_done;
+  CoopSlot slot[kCoopMaxSlots];
+  struct alignas(128) { unsigned long long v; } ready[kCoopReadyRing];  // (entry + 1) << 32 | local transform index
+};
+struct Coop2Ctl {
+  Coop2Xcd x[8];
+  CoopWord next_transform;
+  CoopWord error;
+};
+size_t coop2_ctl_bytes() { return sizeof(Coop2Ctl); }
+
+__device__ __forceinline__ bool xcd_cas(unsigned *p, unsigned expected, unsigned desired) {
+  return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
+}
+
+template <int LOGN, bool FWD, bool SCALE, int SM>
+__global__ __launch_bounds__(256, 3) void k_fft_coop2(cpx *__restrict__ data, cpx *__restrict__ scratch,
+                                                      const cpx *__restrict__ tabs_g, long batch, Coop2Ctl *ctl,
+                                                      int nslots) {
+  using G = FourGeom<LOGN>;
+  static_assert(G::NCB == G::NRB, "task groups of both phases have the same size");
+  constexpr unsigned TPG = G::NCB;
+  constexpr bool A1 = (G::N1 == G::HI), A2 = (G::N2 == G::HI);
+  static_assert(A2, "the row length equals the high twiddle table length for n = 2^14..2^16");
+  constexpr int CTABS = G::LO + G::HI + (A1 ? 0 : G::N1 / 2);
+  __shared__ cpx s_tabs[CTABS];
+  __shared__ cpx s_x[G::SL];
+  __shared__ unsigned s_kind, s_i, s_idx, s_xf;   // kind: 0 exit, 1 phase 1, 2 phase 2, 3 nothing to do yet
+  const int tid = threadIdx.x;
+  {
+    const cpx *g_lo = tabs_g + G::N1 / 2 + G::N2 / 2;
+    for (int i = tid; i < G::LO + G::HI; i += 256) s_tabs[i] = g_lo[i];
+    if constexpr (!A1)
+      for (int i = tid; i < G::N1 / 2; i += 256) s_tabs[G::LO + G::HI + i] = tabs_g[i];
+  }
+  const cpx *tlo = s_tabs, *thi = s_tabs + G::LO;
+  const cpx *tab2 = thi, *tab1 = A1 ? thi : s_tabs + G::LO + G::HI;
+  const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;  // hwreg(HW_REG_XCC_ID, 0, 4)
+  Coop2Xcd *c = &ctl->x[xcc];
+  cpx *sbase = scratch + (long)xcc * nslots * G::N;
+  unsigned *pend = nullptr;   // lane 0: slot record whose phase-1 completion is still to be signalled
+  unsigned pend_i = 0;
+  unsigned idle = 0;
+  // lane 0 holds at most one ticket of each kind (fetch_add claims: no retries, no contention).
+  // It runs whichever is runnable, phase 2 first; a ticket that is not runnable yet is kept while
+  // the workgroup does the other kind of work, so the smallest outstanding ticket of either
+  // kind always has a holder that can (eventually) run it: no deadlock.
+  unsigned p1t = kCoopNone, p2t = kCoopNone;
+
+  for (;;) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains the stores of its previous task
+    __syncthreads();
+    if (tid == 0) {
+      if (pend) {
+        // signal the completed phase-1 task; the 16th completion makes the transform READY
+        CoopSlot *rec = reinterpret_cast<CoopSlot *>(pend);
+        const unsigned use = pend_i / nslots;
+        const unsigned old = xcd_add(&rec->c1, 1u);
+        if (old + 1 == TPG * (use + 1)) {
+          const unsigned pos = xcd_add(&c->ready_tail.v, 1u);
+          (void)__hip_atomic_exchange(&c->ready[pos % kCoopReadyRing].v,
+                                      ((unsigned long long)(pos + 1) << 32) | pend_i, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
+        }
+        pend = nullptr;
+      }
+      unsigned kind = 3, ti = 0, tidx = 0, xf = kCoopNone;
+      if (p2t == kCoopNone) p2t = xcd_add(&c->p2_claim.v, 1u);
+      const unsigned rt = xcd_read(&c->ready_tail.v);
+      if (p2t / TPG < rt) {
+        // ---- my phase-2 ticket is READY ----------------------------------------------
+        const unsigned entry = p2t / TPG;
+        unsigned long long rv;
+        unsigned n = 0;
+        while ((unsigned)((rv = __hip_atomic_load(&c->ready[entry % kCoopReadyRing].v, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)) >> 32) != entry + 1) {
+          __builtin_amdgcn_s_sleep(1);   // the pusher is between its tail increment and its store
+          if (++n > kCoopSpinLimit) { __hip_atomic_store(&ctl->error.v, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        ti = (unsigned)rv;
+        tidx = p2t % TPG;
+        xf = coop_load_slot(&c->slot[ti % nslots]).xf;
+        kind = 2;
+        p2t = kCoopNone;
+      } else {
+        // ---- else my phase-1 ticket, if its transform's slot is usable -------------------
+        if (p1t == kCoopNone) p1t = xcd_add(&c->p1_claim.v, 1u);
+        const unsigned i = p1t / TPG, idx = p1t % TPG;
+        const unsigned endi = 0xFFFFFFFFu - xcd_read(&c->endinv.v);
+        if (i >= endi) {
+          // this XCD has no transform i; leave once my phase-2 ticket is past the last entry too
+          if (p2t / TPG >= endi) kind = 0;
+        } else {
+          CoopSlot *rec = &c->slot[i % nslots];
+          const unsigned use = i / nslots;
+          const CoopSlot v = coop_load_slot(rec);
+          if (idx == 0) {
+            // owner: previous user of the slot fully read, and it is my turn to draw a global index
+            if ((use == 0 || v.c2 >= TPG * use) && xcd_read(&c->draws.v) == i) {
+              const unsigned gi = __hip_atomic_fetch_add(&ctl->next_transform.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((long)gi >= batch) {
+                (void)__hip_atomic_fetch_max(&c->endinv.v, 0xFFFFFFFFu - i, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
+              } else {
+                xf = gi + 1;
+                (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&rec->tag),
+                                            ((unsigned long long)xf << 32) | (unsigned long long)(i + 1),
+                                            __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
+                ti = i;
+                tidx = 0;
+                kind = 1;
+              }
+              xcd_write(&c->draws.v, i + 1);
+              p1t = kCoopNone;
+            }
+          } else if (v.tag == i + 1) {   // the owner has published this transform
+            xf = v.xf;
+            ti = i;
+            tidx = idx;
+            kind = 1;
+            p1t = kCoopNone;
+          }
+        }
+      }
+      if (kind == 3) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++idle > kCoopSpinLimit) {   // never hang the GPU
+          __hip_atomic_store(&ctl->error.v, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          kind = 0;
+        }
+      } else {
+        idle = 0;
+      }
+      s_kind = kind;
+      s_i = ti;
+      s_idx = tidx;
+      s_xf = xf;
+    }
+    __syncthreads();
+    const unsigned kind = s_kind, i = s_i, idx = s_idx, xf = s_xf;
+    if (kind == 0) break;
+    if (kind == 3) continue;
+    CoopSlot *rec = &c->slot[i % nslots];
+    cpx *x = data + (long)(xf - 1) * G::N;
+    cpx *mid = sbase + (long)(i % nslots) * G::N;
+    if (kind == 1) {
+      four_phase1<LOGN, FWD, SM>(x, mid, (int)idx, tid, tab1, tlo, thi, s_x);
+      if (tid == 0) {
+        pend = &rec->c1;
+        pend_i = i;
+      }
+    } else {
+      four_phase2<LOGN, FWD, SCALE, SM, true>(mid, x, (int)idx, tid, tab2, s_x, &rec->c2);
+    }
+  }
+}
+
+template <int LOGN>
+static hipError_t launch_coop2_n(bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
+                                 long batch, const DeviceInfo &di, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(ctl, 0, sizeof(Coop2Ctl), s);
+  if (e != hipSuccess) return e;
+  int grid = di.num_cus * 2;
+  if (const char *g = getenv("CLFA_COOP_GRID")) {
+    int v = atoi(g);
+    if (v > 0) grid = v;
+  }
+  int ns = 4;
+  if (const char *e2 = getenv("CLFA_COOP_SLOTS")) {
+    int v = atoi(e2);
+    if (v >= 2 && v <= kCoopMaxSlots) ns = v;
+  }
+  int sm = 2;
+  if (const char *m = getenv("CLFA_COOP_STREAM")) sm = atoi(m);
+  Coop2Ctl *c = (Coop2Ctl *)ctl;
+#define CLFA_COOP2(F, S, M) hipLaunchKernelGGL((k_fft_coop2<LOGN, F, S, M>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns)
+  if (sm == 2) {
+    if (fwd && scale) CLFA_COOP2(true, true, 2); else if (fwd) CLFA_COOP2(true, false, 2); else CLFA_COOP2(false, false, 2);
+  } else {
+    if (fwd && scale) CLFA_COOP2(true, true, 1); else if (fwd) CLFA_COOP2(true, false, 1); else CLFA_COOP2(false, false, 1);
+  }
+#undef CLFA_COOP2
+  return hipGetLastError();
+}
+
+hipError_t launch_fft_coop2(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
+                            long batch, const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  switch (logn) {
+    case 14: return launch_coop2_n<14>(fwd, scale, data, scratch, ctl, t, batch, di, s);
+    case 15: return launch_coop2_n<15>(fwd, scale, data, scratch, ctl, t, batch, di, s);
+    case 16: return launch_coop2_n<16>(fwd, scale, data, scratch, ctl, t, batch, di, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t coop2_read_error(const void *ctl, unsigned *err, hipStream_t s) {
+  return hipMemcpyAsync(err, &((const Coop2Ctl *)ctl)->error.v, sizeof(unsigned), hipMemcpyDeviceToHost, s);
 }
 
 int coop_slots() {
@@ -725,9 +946,17 @@ static hipError_t launch_coop_n(bool fwd, bool scale, cpx *data, cpx *scratch, v
     if (v >= 1 && v <= 8) lag = v;
   }
   CoopCtl *c = (CoopCtl *)ctl;
-  if (fwd && scale) hipLaunchKernelGGL((k_fft_coop<LOGN, true, true>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns, lag);
-  else if (fwd) hipLaunchKernelGGL((k_fft_coop<LOGN, true, false>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns, lag);
-  else hipLaunchKernelGGL((k_fft_coop<LOGN, false, false>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns, lag);
+  int sm = 1;
+  if (const char *m = getenv("CLFA_COOP_STREAM")) sm = atoi(m);
+#define CLFA_COOP(F, S, M) hipLaunchKernelGGL((k_fft_coop<LOGN, F, S, M>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns, lag)
+  if (sm == 2) {
+    if (fwd && scale) CLFA_COOP(true, true, 2); else if (fwd) CLFA_COOP(true, false, 2); else CLFA_COOP(false, false, 2);
+  } else if (sm == 0) {
+    if (fwd && scale) CLFA_COOP(true, true, 0); else if (fwd) CLFA_COOP(true, false, 0); else CLFA_COOP(false, false, 0);
+  } else {
+    if (fwd && scale) CLFA_COOP(true, true, 1); else if (fwd) CLFA_COOP(true, false, 1); else CLFA_COOP(false, false, 1);
+  }
+#undef CLFA_COOP
   return hipGetLastError();
 }
 

@@ -44,6 +44,12 @@ size_t coop_scratch_bytes(int logn);
 hipError_t launch_fft_coop(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
                            long batch, const DeviceInfo &di, hipStream_t s);
 hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s);
+// readiness-driven cooperative kernel (variant 14)
+constexpr int kVariantCoop2 = 14;
+size_t coop2_ctl_bytes();
+hipError_t launch_fft_coop2(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
+                            long batch, const DeviceInfo &di, hipStream_t s);
+hipError_t coop2_read_error(const void *ctl, unsigned *err, hipStream_t s);
 
 // stand-alone pack / unpack (reference kernels conv / iconv) for M above the LDS path
 hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
