@@ -275,7 +275,17 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   std::vector<cpx> h;
   if (p->logn <= kLdsMaxLog) {
-    fill_twiddle(h, n / 2, n, 1, -1.f);
+    if (kLdsTwoLevel(p->logn)) {
+      // two-level table: hi[j] = W_n^(64 j), j < n/64, then lo[j] = W_n^j, j < 64
+      const int lo = 1 << kLdsTwoLevelLogLo;
+      std::vector<cpx> part;
+      fill_twiddle(h, n / lo, n, lo, -1.f);
+      fill_twiddle(part, lo, n, 1, -1.f);
+      h.resize(n / lo);
+      h.insert(h.end(), part.begin(), part.begin() + lo);
+    } else {
+      fill_twiddle(h, n / 2, n, 1, -1.f);
+    }
     if ((e = upload(p->half, h.data(), sizeof(cpx) * h.size()))) return e;
     p->tabs.half = (const cpx *)p->half.p;
   } else {

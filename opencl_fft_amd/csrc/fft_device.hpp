@@ -113,11 +113,38 @@ template <int U, int E, bool FWD> CLFA_HD void dft16(cpx (&v)[E], int u) {
   }
 }
 
+// 32 = 16 x 2: t = 2a + b, q = q0 + 16*q1.  cos/sin(2 pi k/32), k = 1..15, as float literals.
+constexpr float kC32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                            0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                            0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
+                            -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                            -0.92387953251128675613f, -0.98078528040323044913f};
+constexpr float kS32[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                            0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                            0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
+                            0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                            0.38268343236508977173f, 0.19509032201612826785f};
+template <int U, int E, bool FWD> CLFA_HD void dft32(cpx (&v)[E], int u) {
+  cpx x[32];
+#pragma unroll
+  for (int t = 0; t < 32; t++) x[t] = v[u + U * t];
+  dft16<2, 32, FWD>(x, 0);  // b = 0: inputs x[2a], results q0 at x[2*q0]
+  dft16<2, 32, FWD>(x, 1);  // b = 1: x[2a+1] -> x[2*q0+1]
+#pragma unroll
+  for (int q0 = 0; q0 < 16; q0++) {
+    cpx a = x[2 * q0], b = x[2 * q0 + 1];
+    if (q0 > 0) b = ctw<FWD>(b, kC32[q0], kS32[q0]);  // W_32^q0
+    v[u + U * q0] = cadd(a, b);
+    v[u + U * (q0 + 16)] = csub(a, b);
+  }
+}
+
 template <int LOGR, int U, int E, bool FWD> CLFA_HD void dft(cpx (&v)[E], int u) {
   if constexpr (LOGR == 1) dft2<U, E, FWD>(v, u);
   else if constexpr (LOGR == 2) dft4<U, E, FWD>(v, u);
   else if constexpr (LOGR == 3) dft8<U, E, FWD>(v, u);
   else if constexpr (LOGR == 4) dft16<U, E, FWD>(v, u);
+  else if constexpr (LOGR == 5) dft32<U, E, FWD>(v, u);
 }
 
 // ---- Stockham pass schedule ---------------------------------------------------
@@ -142,6 +169,19 @@ template <int LOGN, bool FWD, class Tab> CLFA_HD cpx tw_lookup(const Tab &tab, i
   return w;
 }
 
+// Two-level twiddle table: W_n^k = hi[k >> LOGLO] * lo[k & (2^LOGLO - 1)], hi[j] = W_n^(j * 2^LOGLO),
+// lo[j] = W_n^j, both rounded from double.  n/2^LOGLO + 2^LOGLO entries instead of n/2: it lets
+// the 8192-point kernel keep two workgroups per CU.  One extra complex multiply per lookup.
+template <int LOGLO> struct TwoLevelTab {
+  const cpx *hi;
+  const cpx *lo;
+};
+template <int LOGN, bool FWD, int LOGLO> CLFA_HD cpx tw_lookup(const TwoLevelTab<LOGLO> &tab, int k) {
+  cpx w = cmul(tab.hi[k >> LOGLO], tab.lo[k & ((1 << LOGLO) - 1)]);
+  if (!FWD) w.y = -w.y;
+  return w;
+}
+
 // One pass on the registers of lane `tid`: input twiddles then U butterflies.
 template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
 CLFA_HD void pass_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
@@ -155,6 +195,13 @@ CLFA_HD void pass_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
       for (int t = 1; t < R; t++) {
         int k = (jm * t) << (LOGN - LOGNS - LOGR);
         v[u + U * t] = cmul(v[u + U * t], tw_lookup<LOGN, FWD>(tab, k));
+#if defined(__HIP_DEVICE_COMPILE__)
+        // with 32 points per lane hipcc otherwise hoists every table read of the pass ahead of
+        // the multiplies (100+ live VGPRs of twiddles) and spills: fence the scheduler every 4
+        if constexpr (E == 32) {
+          if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
     }
   }

@@ -46,18 +46,25 @@ __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const c
 }
 
 template <int LOGN, bool FWD, int MODE, bool SCALE>
-__global__ __launch_bounds__(LdsGeom<LOGN>::WG) void k_fft_lds(cpx *__restrict__ data,
+__global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k_fft_lds(cpx *__restrict__ data,
                                                               const cpx *__restrict__ tab_g,
                                                               const cpx *__restrict__ w2_g, long batch) {
   using G = LdsGeom<LOGN>;
   constexpr int N = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
-  __shared__ cpx s_tab[G::HALF];
+  // twiddles in LDS: half table W_n^k (k < n/2), or for n = 8192 the two-level table
+  // [hi: W_n^(64 j), j < n/64 | lo: W_n^j, j < 64] that keeps the block at 71 KiB
+  constexpr bool TWO = kLdsTwoLevel(LOGN);
+  constexpr int NHI = N >> kLdsTwoLevelLogLo, NLO = 1 << kLdsTwoLevelLogLo;
+  constexpr int NTAB = TWO ? NHI + NLO : G::HALF;
+  __shared__ cpx s_tab[NTAB];
   __shared__ cpx s_x[FPW * G::PADN];
 
   const int tid = threadIdx.x;
   const int f = tid / T, t = tid % T;
-  for (int i = tid; i < N / 2; i += WG) s_tab[i] = tab_g[i];
+  for (int i = tid; i < (TWO ? NTAB : N / 2); i += WG) s_tab[i] = tab_g[i];
   cpx *xb = s_x + f * G::PADN;
+  const TwoLevelTab<kLdsTwoLevelLogLo> tab2{s_tab, s_tab + NHI};
+  const cpx *tab1 = s_tab;
 
   // pack / unpack twiddles of this lane's pairs are the same for every transform
   constexpr int NP = (MODE == MODE_C2C) ? 1 : (E / 2 > 0 ? E / 2 : 1);
@@ -78,14 +85,22 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG) void k_fft_lds(cpx *__restrict__
 #pragma unroll
     for (int e = 0; e < E; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
   }
+  const int t_invariant = t;
 #pragma unroll 1
   for (; g < groups; g += gridDim.x) {
+    // Re-derive the lane index inside the loop through an opaque move: otherwise hipcc hoists every
+    // LDS scatter/gather offset and global offset of all passes out of the batch loop, keeps
+    // ~100 of them live across it and spills them (seen in the ISA as scratch stores in the
+    // prologue and scratch loads in the loop).  Recomputing them costs a few VALU instructions.
+    int t = t_invariant;
+    asm volatile("" : "+v"(t));
     const long b = g * FPW + f;
     const bool active = b < batch;
     cpx *x = data + (active ? b : batch - 1) * (long)N;
     // software prefetch: the next transform's loads fly while this one is in the passes.
     // Always issued (index clamped to the last transform) so that it is straight-line code.
-    {
+    // (not for n = 8192: there two workgroups per CU overlap each other instead)
+    if constexpr (G::PREFETCH) {
       long gn = g + gridDim.x;
       gn = gn < groups ? gn : groups - 1;
       const long bn = gn * FPW + f;
@@ -111,7 +126,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG) void k_fft_lds(cpx *__restrict__
       pass_gather<LOGN, G::LOGE>(v, t, [&](int p) { return xb[lds_pad(p)]; });
     }
 
-    wg_passes<LOGN, G::LOGE, 0, FWD>(v, t, s_tab, xb);
+    if constexpr (TWO) wg_passes<LOGN, G::LOGE, 0, FWD>(v, t, tab2, xb);
+    else wg_passes<LOGN, G::LOGE, 0, FWD>(v, t, tab1, xb);
 
     if constexpr (SCALE) {
       constexpr float inv = 1.0f / (float)N;
@@ -151,10 +167,18 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG) void k_fft_lds(cpx *__restrict__
     // Consume the prefetch HERE, in straight-line code after the stores: hipcc then waits with an
     // exact s_waitcnt vmcnt(<stores still in flight>).  If the first use were at the loop top, the
     // wait would be merged with the loop-entry path and drain this iteration's stores as well.
+    if constexpr (G::PREFETCH) {
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-      asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
-      v[e] = vn[e];
+      for (int e = 0; e < E; e++) {
+        asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
+        v[e] = vn[e];
+      }
+    } else {
+      // no prefetch: load the next transform now (clamped, straight-line)
+      long gn = g + gridDim.x;
+      gn = gn < groups ? gn : groups - 1;
+      const long bn = gn * FPW + f;
+      lds_fft_load<LOGN, MODE>(v, data + (bn < batch ? bn : batch - 1) * (long)N, t);
     }
   }
 }

@@ -5,8 +5,8 @@
 
 namespace clfa {
 
-template <int LOGN, int LOGE, int LOGNS, bool FWD>
-__device__ __forceinline__ void wg_passes(cpx (&v)[1 << LOGE], int t, const cpx *tab, cpx *xb) {
+template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
+__device__ __forceinline__ void wg_passes(cpx (&v)[1 << LOGE], int t, const Tab &tab, cpx *xb) {
   pass_compute<LOGN, LOGE, LOGNS, FWD>(v, t, tab);
   constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
   if constexpr (LOGNS + LOGR < LOGN) {
@@ -20,7 +20,13 @@ __device__ __forceinline__ void wg_passes(cpx (&v)[1 << LOGE], int t, const cpx 
 
 template <int LOGN> struct LdsGeom {
   static constexpr int N = 1 << LOGN;
+  // 16 points per lane.  (32 points per lane with radix-32 passes was measured for n = 8192:
+  // slower — 4.08 vs 4.38 TB/s — so the radix-32 butterfly stays in fft_device.hpp unused here.)
   static constexpr int LOGE = cmin(4, LOGN);
+  // n = 8192 runs WITHOUT the register prefetch but capped at 128 VGPRs, so that two 512-lane
+  // workgroups share a CU (LDS 71 KiB each thanks to the two-level twiddle table)
+  static constexpr bool PREFETCH = LOGN <= 12;
+  static constexpr int MIN_WAVES = LOGN >= 13 ? 4 : 1;
   static constexpr int E = 1 << LOGE;
   static constexpr int T = N / E;                       // lanes per transform
   static constexpr int WG = T >= 256 ? T : 256;         // threads per workgroup

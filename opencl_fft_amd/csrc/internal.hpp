@@ -11,6 +11,9 @@ enum FftMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2 };
 // Largest complex length the single-workgroup LDS kernel handles; above it
 // the four-step kernel (two phases through an on-die scratch) takes over.
 constexpr int kLdsMaxLog = 13;
+// complex lengths whose LDS kernel uses the two-level twiddle table [hi (n/64) | lo (64)]
+constexpr int kLdsTwoLevelLogLo = 6;
+constexpr bool kLdsTwoLevel(int logn) { return logn >= 13; }
 constexpr int kMaxLog = 16;  // reference int32 index bound, cl_fft.cpp:32
 
 struct FftTables {      // all device pointers, owned by the plan
@@ -78,9 +81,6 @@ hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *rin
 // tail channels x pts (unscaled second half kept for the next block)
 hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail, float *out,
                                 const cpx *half, const cpx *w2i, hipStream_t s);
-// fused: MAC + inverse in one kernel (one workgroup per channel)
-hipError_t launch_pconv_mac_inverse(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp,
-                                    float *tail, float *out, const cpx *half, const cpx *w2i, hipStream_t s);
 constexpr int kPconvMaxLogBins = 15;   // pts up to 32768 (the reference harness' largest, csound/tests.py:13)
 // ends of the composed chain used when bins exceed the LDS FFT sizes
 hipError_t launch_pconv_pad(const float *in, long in_stride, cpx *work, int bins, int channels, hipStream_t s);

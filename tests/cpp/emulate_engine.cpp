@@ -73,6 +73,49 @@ template <int LOGN, int LOGE, bool FWD> static double check() {
 }
 
 static int g_fail = 0;
+// same engine with the two-level twiddle table (W_n^k = hi[k >> LOGLO] * lo[k & mask])
+template <int LOGN, int LOGE, int LOGNS, bool FWD, int LOGLO>
+static void run2(std::vector<cpx> &regs, const TwoLevelTab<LOGLO> &tab, std::vector<cpx> &lds) {
+  constexpr int E = 1 << LOGE, T = 1 << (LOGN - LOGE);
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
+  for (int tid = 0; tid < T; tid++)
+    pass_compute<LOGN, LOGE, LOGNS, FWD>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, tab);
+  if constexpr (LOGNS + LOGR < LOGN) {
+    for (int tid = 0; tid < T; tid++)
+      pass_scatter<LOGN, LOGE, LOGNS>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid,
+                                      [&](int p, cpx v) { lds[lds_pad(p)] = v; });
+    for (int tid = 0; tid < T; tid++)
+      pass_gather<LOGN, LOGE>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, [&](int p) { return lds[lds_pad(p)]; });
+    run2<LOGN, LOGE, LOGNS + LOGR, FWD, LOGLO>(regs, tab, lds);
+  }
+}
+template <int LOGN, int LOGE, int LOGLO, bool FWD> static int two_level() {
+  constexpr int n = 1 << LOGN, E = 1 << LOGE, T = n / E, LO = 1 << LOGLO, HI = n >> LOGLO;
+  std::vector<cpx> x(n), hi(HI), lo(LO), regs(n), regs1(n), lds(lds_padded_size(n)), half(n / 2);
+  unsigned s = 777u;
+  for (auto &c : x) {
+    s = s * 1664525u + 1013904223u; c.x = (float)(s >> 8) / 8388608.0f - 1.0f;
+    s = s * 1664525u + 1013904223u; c.y = (float)(s >> 8) / 8388608.0f - 1.0f;
+  }
+  const double PI = 3.141592653589793;
+  for (int i = 0; i < HI; i++) hi[i] = mk((float)cos((double)i * LO * 2 * PI / n), -(float)sin((double)i * LO * 2 * PI / n));
+  for (int i = 0; i < LO; i++) lo[i] = mk((float)cos(i * 2 * PI / n), -(float)sin(i * 2 * PI / n));
+  for (int i = 0; i < n / 2; i++) half[i] = mk((float)cos(i * 2 * PI / n), -(float)sin(i * 2 * PI / n));
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) regs1[tid * E + e] = regs[tid * E + e] = x[tid + T * e];
+  TwoLevelTab<LOGLO> tab{hi.data(), lo.data()};
+  run2<LOGN, LOGE, 0, FWD, LOGLO>(regs, tab, lds);
+  run<LOGN, LOGE, 0, FWD>(regs1, half, lds);      // exact half table as the yardstick
+  double num = 0, den = 0;
+  for (int i = 0; i < n; i++) {
+    double dx = regs[i].x - regs1[i].x, dy = regs[i].y - regs1[i].y;
+    num += dx * dx + dy * dy;
+    den += (double)regs1[i].x * regs1[i].x + (double)regs1[i].y * regs1[i].y;
+  }
+  double e = sqrt(num / den);
+  printf("n=2^%-2d E=%-2d two-level table vs exact table: relL2 %.3g\n", LOGN, E, e);
+  return !(e < 3e-7);
+}
 template <int LOGN, int LOGE> static void both() {
   double a = check<LOGN, LOGE, true>(), b = check<LOGN, LOGE, false>();
   printf("n=2^%-2d E=%-2d relL2 fwd %.3g inv %.3g\n", LOGN, 1 << LOGE, a, b);
@@ -83,6 +126,8 @@ int main() {
   both<1, 1>(); both<2, 2>(); both<3, 3>(); both<4, 4>(); both<5, 4>(); both<6, 4>(); both<7, 4>();
   both<8, 4>(); both<9, 4>(); both<10, 4>(); both<11, 4>(); both<12, 4>(); both<13, 4>(); both<14, 4>();
   both<6, 2>(); both<6, 3>(); both<10, 3>(); both<9, 2>(); both<7, 3>(); both<8, 3>();
+  both<5, 5>(); both<10, 5>(); both<13, 5>(); both<12, 5>(); both<8, 5>();   // 32 points per lane (radix-32 passes)
+  g_fail |= two_level<13, 5, 6, true>() | two_level<13, 5, 6, false>() | two_level<12, 4, 6, true>();
   puts(g_fail ? "FAIL" : "OK");
   return g_fail;
 }
