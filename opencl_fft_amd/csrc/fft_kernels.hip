@@ -442,6 +442,36 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
   }
 }
 
+// Small batches (fewer transforms than resident workgroups): one workgroup per column block,
+// then one per row block — two launches, N2/C1 workgroups per transform, instead of one
+// persistent workgroup walking all 32 blocks of its transform serially (86 us for batch 1).
+template <int LOGN, bool FWD>
+__global__ __launch_bounds__(256) void k_fft_4step_cols(const cpx *__restrict__ data, cpx *__restrict__ scratch,
+                                                        const cpx *__restrict__ tabs_g) {
+  using G = FourGeom<LOGN>;
+  __shared__ cpx s_tabs[G::TABS];
+  __shared__ cpx s_x[G::SL];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < G::TABS; i += 256) s_tabs[i] = tabs_g[i];
+  const cpx *tab1 = s_tabs, *tlo = s_tabs + G::N1 / 2 + G::N2 / 2, *thi = tlo + G::LO;
+  __syncthreads();
+  const long b = blockIdx.y;
+  four_phase1<LOGN, FWD, 0>(data + b * (long)G::N, scratch + b * (long)G::N, blockIdx.x, tid, tab1, tlo, thi, s_x);
+}
+template <int LOGN, bool FWD, bool SCALE>
+__global__ __launch_bounds__(256) void k_fft_4step_rows(cpx *__restrict__ data, const cpx *__restrict__ scratch,
+                                                        const cpx *__restrict__ tabs_g) {
+  using G = FourGeom<LOGN>;
+  __shared__ cpx s_tabs[G::TABS];
+  __shared__ cpx s_x[G::SL];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < G::TABS; i += 256) s_tabs[i] = tabs_g[i];
+  const cpx *tab2 = s_tabs + G::N1 / 2;
+  __syncthreads();
+  const long b = blockIdx.y;
+  four_phase2<LOGN, FWD, SCALE, 0>(scratch + b * (long)G::N, data + b * (long)G::N, blockIdx.x, tid, tab2, s_x);
+}
+
 struct FourVariant {
   int nslice;
   bool nt;
@@ -484,6 +514,14 @@ static hipError_t launch_4step_v(int variant, cpx *data, cpx *scratch, const Fft
                                  const DeviceInfo &di, hipStream_t s) {
   FourVariant v = four_variant(variant);
   int grid = fourstep_grid(LOGN, variant, di);
+  if (batch * 4 <= grid && batch <= 65535) {
+    // few transforms: spread each over its column / row blocks (scratch holds `grid` transforms)
+    using G = FourGeom<LOGN>;
+    hipLaunchKernelGGL((k_fft_4step_cols<LOGN, FWD>), dim3(G::NCB, (unsigned)batch), dim3(256), 0, s, data, scratch, t.four);
+    hipLaunchKernelGGL((k_fft_4step_rows<LOGN, FWD, SCALE>), dim3(G::NRB, (unsigned)batch), dim3(256), 0, s, data, scratch,
+                       t.four);
+    return hipGetLastError();
+  }
   if (batch < grid) grid = (int)batch;
 #define CLFA_V(NS, NT, PF)                                                                                  \
   if (v.nslice == NS && v.nt == NT && v.pf == PF) {                                                         \

@@ -179,3 +179,44 @@ def test_dconv_time_varying_vs_oracle():
         assert d.convolution(out, x1[sl], x2[sl]) == 0
         want = o.convolution(x1[sl], x2[sl])
         assert np.max(np.abs(out - want)) <= 5e-6 * max(1e-3, np.max(np.abs(want)))
+
+
+def test_config4_full_size_properties():
+    """config 4 of BASELINE.json at full size: 256 channels, pts 1024, 94 partitions, device-resident.
+    Three channels against the oracle, linearity (conv(a x) = a conv(x)) and channel independence on all."""
+    import torch
+    pts, cvs, channels, blocks = 1024, 96256, 256, 4
+    g = torch.Generator(device="cuda").manual_seed(4)
+    ir = (torch.rand((channels, cvs), generator=g, device="cuda") - 0.5) / (cvs ** 0.5)
+    x = torch.rand((blocks, channels, pts), generator=g, device="cuda") * 2 - 1
+    gain = torch.linspace(0.5, 2.0, channels, device="cuda").reshape(1, channels, 1)
+
+    def run(inp):
+        p = fa.Clpconv(0, cvs, pts, channels=channels)
+        assert p.get_cl_err() == 0 and p.nparts == 94
+        assert p.push_ir_device(ir) == 0
+        outs = []
+        for b in range(blocks):
+            o = torch.empty((channels, pts), device="cuda")
+            assert p.process_device(o, inp[b].contiguous()) == 0
+            outs.append(o)
+        torch.cuda.synchronize()
+        return torch.stack(outs)
+
+    y = run(x)
+    y2 = run(x * gain)
+    rel = float(((y2 - y * gain).double().norm() / (y * gain).double().norm()))
+    assert rel < 1e-6, rel
+    # channel independence: permuting the channels permutes the outputs
+    perm = torch.randperm(channels, generator=torch.Generator().manual_seed(1)).cuda()
+    ir_saved = ir
+    ir = ir_saved[perm].contiguous()
+    y3 = run(x[:, perm].contiguous())
+    ir = ir_saved
+    assert float((y3 - y[:, perm]).abs().max()) <= 2e-6 * float(y.abs().max())
+    ir_h, x_h, y_h = ir.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy()
+    for c in (0, 127, 255):
+        o = oracle.Pconv(cvs, pts)
+        o.push_ir(ir_h[c])
+        want = np.stack([o.convolution(x_h[b, c]) for b in range(blocks)])
+        assert_parity(y_h[:, c], want, tol=CTOL, what="channel %d" % c)
