@@ -87,11 +87,17 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
         a.gpus = world
+    # rehearsal hooks (tests only): CLFA_BENCH_BACKEND=gloo CLFA_BENCH_DEVICE=0 run several ranks on ONE GPU
+    backend = os.environ.get("CLFA_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("CLFA_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI: one rank per GPU
+        else:
+            dist.init_process_group(backend)
 
     from opencl_fft_amd.dist import ShardedBatch
 

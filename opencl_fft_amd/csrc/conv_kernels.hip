@@ -100,6 +100,17 @@ struct alignas(16) cpx2 {
   cpx a, b;
 };
 
+// both rings are read exactly once per block and exceed the Infinity Cache at config 4:
+// non-temporal 16-byte loads
+__device__ __forceinline__ cpx2 ld_stream(const cpx2 *p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f r = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+  cpx2 o;
+  o.a = mk(r.x, r.y);
+  o.b = mk(r.z, r.w);
+  return o;
+}
+
 // one lane = two adjacent bins (16 B) of one channel; loops the partitions of its segment.
 // blockIdx.y = segment of the partition axis (1 segment when there are enough channels to fill
 // the chip; few channels with long filters are split and summed by k_pconv_reduce in fixed order)
@@ -126,8 +137,8 @@ __global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, co
       for (int u = 0; u < UNROLL; u++) {
         int f = fr + u;
         f = f < nparts ? f : f - nparts;
-        av[u] = a[(long)f * hb];
-        bv[u] = b[(long)(p + u) * hb];
+        av[u] = ld_stream(a + (long)f * hb);
+        bv[u] = ld_stream(b + (long)(p + u) * hb);
       }
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) {

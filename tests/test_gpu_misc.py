@@ -1,0 +1,105 @@
+"""Boundary behaviour beyond numerics: independent objects on different host threads (the reference's
+objects share no globals), plan churn, and the bench.py JSON contract."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import opencl_fft_amd as fa
+from oracle import oracle
+from tests import util
+from tests.util import assert_parity
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_independent_objects_on_threads():
+    sizes = [256, 1024, 4096, 65536, 16384, 8192]
+    results, errors = {}, []
+
+    def work(k, n):
+        try:
+            x = util.lcg_complex(100 + k, n * 3).reshape(3, n)
+            f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+            for _ in range(5):
+                y = x.copy()
+                assert f.transform(y) == 0
+                z = y.copy()
+                assert i.transform(z) == 0
+            results[k] = (x, y, z)
+        except Exception as e:      # noqa: BLE001 - reported below
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k, n)) for k, n in enumerate(sizes)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for k, n in enumerate(sizes):
+        x, y, z = results[k]
+        assert_parity(y, oracle.cfft(x, True), what="thread %d n=%d" % (k, n))
+        assert_parity(z, x, what="round trip thread %d" % k)
+
+
+def test_plan_churn_does_not_leak_or_fail():
+    x = util.lcg_complex(5, 65536)
+    want = oracle.cfft(x, True)
+    for _ in range(40):                      # each plan owns a stream, tables and 256 MiB of scratch
+        p = fa.Clcfft(0, 65536, True)
+        assert p.get_error() == 0
+        y = x.copy()
+        assert p.transform(y) == 0
+        del p
+    assert_parity(y, want, what="after churn")
+
+
+def test_device_tensor_must_be_contiguous():
+    import torch
+    d = torch.zeros((4, 1024, 2), device="cuda")[:, ::2]
+    with pytest.raises(ValueError):
+        fa.Clcfft(0, 512, True).exec_device(d, 4)
+
+
+@pytest.mark.parametrize("workload,extra", [("c2c", ["--batch", "64"]), ("rfft", ["--batch", "128"]),
+                                            ("pconv", ["--batch", "8"])])
+def test_bench_contract(workload, extra):
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
+                                   "--workload", workload] + extra, stderr=subprocess.DEVNULL, timeout=300).decode()
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    r = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 4 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["higher_is_better"] is True and r["vs_baseline"] is None and r["dtype"] == "f32" and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["achieved"] > 0
+    if workload == "c2c":
+        cb = r["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+        assert r["config"]["parity_relL2_vs_oracle"] < 1e-6
+
+
+def test_bench_two_rank_rehearsal():
+    """the N>1 launch line of the driver (torch.distributed.run, one process per rank), rehearsed on one
+    GPU: gloo backend, both ranks on device 0.  Checks the max-over-ranks / whole-job aggregation."""
+    env = dict(os.environ, CLFA_BENCH_BACKEND="gloo", CLFA_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--batch", "256"]
+    out = subprocess.check_output(cmd, env=env, stderr=subprocess.DEVNULL, timeout=600).decode()
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out            # only rank 0 prints
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["cpu_baseline"] is None
+    assert r["config"]["global_batch"] == 512 and r["config"]["shard_start"] == 0
+    # whole-job value = samples of BOTH ranks over the max time
+    expect = 2 * 256 * 65536 * 4 / (r["ms_per_step"] * 4 * 1e-3) / 1e9
+    assert abs(r["value"] - expect) / expect < 1e-6
