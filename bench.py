@@ -156,7 +156,7 @@ def main():
         step = lambda k: pc.process_device(out, inp, None, stream.cuda_stream)
         workload = ("partitioned convolution, %d channels per GPU, pts=1024, IR 96256 (94 partitions), 48 kHz "
                     "(BASELINE configs[3])" % ch)
-        kernel, tkey = "k_pconv_mac", "pconv1024x94"
+        kernel, tkey = "k_pconv_fused", "pconv1024x94"
         metric, unit = "channel-samples/s for partitioned convolution (x1e9)", "Gsamples/s"
         extra["realtime_ratio_per_channel_denominator_s"] = pts / 48000.0
 

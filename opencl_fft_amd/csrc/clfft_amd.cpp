@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -632,6 +633,16 @@ int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void
   HIP_TRY(hipSetDevice(p->di.device));
   hipStream_t s = (hipStream_t)stream;
   int e;
+  if (pconv_fused_ok(p->g, p->di) && !getenv("CLFA_PCONV_NO_FUSE")) {
+    // whole block in one launch; ring indices advance exactly as below
+    const int frame1 = p->wp, frame2 = p->wp2;
+    p->wp = p->wp != p->g.nparts - 1 ? p->wp + 1 : 0;
+    if (in2) p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;
+    HIP_TRY(launch_pconv_fused(p->g, (const float *)in1, (const float *)in2, (cpx *)p->ringA.p, (cpx *)p->ringB.p,
+                               (float *)p->tail.p, (float *)out, frame1, frame2, p->wp, (const cpx *)p->half.p,
+                               (const cpx *)p->w2f.p, (const cpx *)p->w2i.p, s));
+    return CLFA_SUCCESS;
+  }
   // forward chain(s): cl_conv.cpp:399-419 / 465-513
   if ((e = pconv_forward(p, (const float *)in1, p->pts, (cpx *)p->ringA.p, p->wp, s))) return e;
   if (in2 && (e = pconv_forward(p, (const float *)in2, p->pts, (cpx *)p->ringB.p, p->wp2, s))) return e;

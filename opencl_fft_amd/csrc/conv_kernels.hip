@@ -293,6 +293,203 @@ hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail,
 }
 
 // ---------------------------------------------------------------------------------
+// fused block: forward FFT -> MAC over all partitions -> inverse FFT + overlap-add, one
+// workgroup per channel, ONE launch per block (used when there are enough channels to fill the
+// chip).  Everything a channel needs stays inside its workgroup, so the only synchronisation is
+// __syncthreads(): the new spectrum frame is stored to the ring and re-read by the same
+// workgroup (workgroup-scope visibility), the accumulator lives in LDS.
+// ---------------------------------------------------------------------------------
+template <int LOGB, bool TV>
+__global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ in1, const float *__restrict__ in2,
+                                                     cpx *__restrict__ ringA, cpx *__restrict__ ringB,
+                                                     float *__restrict__ tail, float *__restrict__ out, int frame1,
+                                                     int frame2, int wp, int nparts, const cpx *__restrict__ tab_g,
+                                                     const cpx *__restrict__ w2f_g, const cpx *__restrict__ w2i_g) {
+  using G = LdsGeom<LOGB>;
+  constexpr int N = G::N, E = G::E, T = G::T;   // N = bins; T = N/16 lanes run the FFTs
+  static_assert(T <= 256 && N / 2 >= 256, "fused block kernel covers bins 512..4096");
+  constexpr int HB = N / 2, IPT = HB / 256;     // 16-byte items (two bins) per lane in the MAC
+  __shared__ cpx s_tab[G::HALF];
+  __shared__ cpx s_x[G::PADN];
+  __shared__ cpx s_acc[N];
+  const int tid = threadIdx.x;
+  const int ch = blockIdx.x;
+  for (int i = tid; i < N / 2; i += 256) s_tab[i] = tab_g[i];
+  __syncthreads();
+
+  // ---- forward chain(s): reference reorder + fft + r2c (cl_conv.cpp:399-419 / 465-513) ----------
+  auto forward = [&](const float *in, cpx *ring, int frame) {
+    cpx v[E];
+    if (tid < T) {
+      const cpx *src = reinterpret_cast<const cpx *>(in + (long)ch * N);
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int p = tid + T * e;
+        v[e] = p < N / 2 ? src[p] : mk(0.f, 0.f);
+      }
+    }
+    // all 256 lanes walk the barriers; lanes >= T carry dummies and touch no LDS slot of the transform
+    if (tid < T) pass_compute<LOGB, G::LOGE, 0, true>(v, tid, s_tab);
+    constexpr int LOGR0 = pass_logr(LOGB, G::LOGE, 0);
+    static_assert(LOGR0 == 4, "16 points per lane");
+    // unrolled pass chain with workgroup-wide barriers
+    __syncthreads();
+    if (tid < T) pass_scatter<LOGB, G::LOGE, 0>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+    __syncthreads();
+    if (tid < T) {
+      pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+      pass_compute<LOGB, G::LOGE, 4, true>(v, tid, s_tab);
+    }
+    if constexpr (LOGB > 8) {
+      __syncthreads();
+      if (tid < T) pass_scatter<LOGB, G::LOGE, 4>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+      __syncthreads();
+      if (tid < T) {
+        pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+        pass_compute<LOGB, G::LOGE, 8, true>(v, tid, s_tab);
+      }
+    }
+    __syncthreads();
+    if (tid < T) {
+#pragma unroll
+      for (int e = 0; e < E; e++) s_x[lds_pad(tid + T * e)] = v[e];
+    }
+    __syncthreads();
+    cpx *x = ring + ((long)ch * nparts + frame) * N;
+    for (int i = tid; i < N / 2; i += 256) {
+      const int j = i == 0 ? N / 2 : N - i;
+      const cpx ci = s_x[lds_pad(i)], cj = s_x[lds_pad(j)];
+      cpx oi, oj;
+      r2c_pair(ci, cj, w2f_g[i], oi, oj);
+      if (i == 0) {
+        oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
+        oj = cj;
+      }
+      x[i] = oi;
+      x[j] = oj;
+    }
+  };
+  forward(in1, ringA, frame1);
+  if constexpr (TV) forward(in2, ringB, frame2);
+  __syncthreads();   // the frames just stored are re-read below by this workgroup
+
+  // ---- MAC over all partitions (reference convol, cl_conv_kernels.h:102-118) -----------------------
+  {
+    const cpx2 *a = reinterpret_cast<const cpx2 *>(ringA + (long)ch * nparts * N);
+    const cpx2 *b = reinterpret_cast<const cpx2 *>(ringB + (long)ch * nparts * N);
+    cpx s0[IPT], s1[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; k++) s0[k] = s1[k] = mk(0.f, 0.f);
+    int fr = wp;
+#pragma unroll 4
+    for (int p = 0; p < nparts; p++) {
+      cpx2 av[IPT], bv[IPT];
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        av[k] = ld_stream(a + (long)fr * HB + tid + 256 * k);
+        bv[k] = ld_stream(b + (long)p * HB + tid + 256 * k);
+      }
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        if (k == 0 && tid == 0) {  // packed DC / Nyquist bin: (re*re, im*im)
+          s0[k].x += av[k].a.x * bv[k].a.x;
+          s0[k].y += av[k].a.y * bv[k].a.y;
+        } else {
+          s0[k] = cadd(s0[k], cmul(av[k].a, bv[k].a));
+        }
+        s1[k] = cadd(s1[k], cmul(av[k].b, bv[k].b));
+      }
+      fr = fr + 1 < nparts ? fr + 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      s_acc[2 * (tid + 256 * k)] = s0[k];
+      s_acc[2 * (tid + 256 * k) + 1] = s1[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- inverse chain: c2r + inverse FFT + overlap-add (cl_conv_kernels.h:87-100, 120-124) -------------
+  for (int i = tid; i < N / 2; i += 256) {
+    if (i == 0) {
+      const cpx c0 = s_acc[0];
+      s_x[0] = mk(c0.x + c0.y, c0.x - c0.y);
+      s_x[lds_pad(N / 2)] = s_acc[N / 2];
+    } else {
+      cpx oi, oj;
+      c2r_pair(s_acc[i], s_acc[N - i], w2i_g[i], oi, oj);
+      s_x[lds_pad(i)] = oi;
+      s_x[lds_pad(N - i)] = oj;
+    }
+  }
+  __syncthreads();
+  {
+    cpx v[E];
+    if (tid < T) {
+      pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+      pass_compute<LOGB, G::LOGE, 0, false>(v, tid, s_tab);
+    }
+    __syncthreads();
+    if (tid < T) pass_scatter<LOGB, G::LOGE, 0>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+    __syncthreads();
+    if (tid < T) {
+      pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+      pass_compute<LOGB, G::LOGE, 4, false>(v, tid, s_tab);
+    }
+    if constexpr (LOGB > 8) {
+      __syncthreads();
+      if (tid < T) pass_scatter<LOGB, G::LOGE, 4>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+      __syncthreads();
+      if (tid < T) {
+        pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+        pass_compute<LOGB, G::LOGE, 8, false>(v, tid, s_tab);
+      }
+    }
+    if (tid < T) {
+      constexpr float inv = 1.0f / (float)N;
+      cpx *o = reinterpret_cast<cpx *>(out + (long)ch * N);
+      cpx *tl = reinterpret_cast<cpx *>(tail + (long)ch * N);
+#pragma unroll
+      for (int e = 0; e < E / 2; e++) {
+        const int p = tid + T * e;
+        const cpx old = tl[p];
+        o[p] = mk((v[e].x + old.x) * inv, (v[e].y + old.y) * inv);
+        tl[p] = v[e + E / 2];
+      }
+    }
+  }
+}
+
+bool pconv_fused_ok(const PconvGeom &g, const DeviceInfo &di) {
+  return g.logb >= 9 && g.logb <= 12 && g.channels * 2 >= di.num_cus;
+}
+
+template <int LOGB>
+static hipError_t launch_fused_one(const PconvGeom &g, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
+                                   float *tail, float *out, int frame1, int frame2, int wp, const cpx *half,
+                                   const cpx *w2f, const cpx *w2i, hipStream_t s) {
+  if (in2)
+    hipLaunchKernelGGL((k_pconv_fused<LOGB, true>), dim3(g.channels), dim3(256), 0, s, in1, in2, ringA, ringB, tail, out,
+                       frame1, frame2, wp, g.nparts, half, w2f, w2i);
+  else
+    hipLaunchKernelGGL((k_pconv_fused<LOGB, false>), dim3(g.channels), dim3(256), 0, s, in1, in2, ringA, ringB, tail, out,
+                       frame1, frame2, wp, g.nparts, half, w2f, w2i);
+  return hipGetLastError();
+}
+
+hipError_t launch_pconv_fused(const PconvGeom &g, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
+                              float *tail, float *out, int frame1, int frame2, int wp, const cpx *half,
+                              const cpx *w2f, const cpx *w2i, hipStream_t s) {
+  switch (g.logb) {
+    case 9: return launch_fused_one<9>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s);
+    case 10: return launch_fused_one<10>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s);
+    case 11: return launch_fused_one<11>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s);
+    case 12: return launch_fused_one<12>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // partitions above the LDS sizes (pts = 16384, 32768): the same chain composed from the
 // large-N FFT kernel; these two kernels are its zero-padding and overlap-add ends
 // ---------------------------------------------------------------------------------

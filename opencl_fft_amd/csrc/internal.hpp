@@ -81,6 +81,12 @@ hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *rin
 // tail channels x pts (unscaled second half kept for the next block)
 hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail, float *out,
                                 const cpx *half, const cpx *w2i, hipStream_t s);
+// one launch per block (forward + MAC + inverse in one workgroup per channel); used when
+// pconv_fused_ok(): bins 512..4096 and enough channels to fill the chip
+bool pconv_fused_ok(const PconvGeom &g, const DeviceInfo &di);
+hipError_t launch_pconv_fused(const PconvGeom &g, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
+                              float *tail, float *out, int frame1, int frame2, int wp, const cpx *half,
+                              const cpx *w2f, const cpx *w2i, hipStream_t s);
 constexpr int kPconvMaxLogBins = 15;   // pts up to 32768 (the reference harness' largest, csound/tests.py:13)
 // ends of the composed chain used when bins exceed the LDS FFT sizes
 hipError_t launch_pconv_pad(const float *in, long in_stride, cpx *work, int bins, int channels, hipStream_t s);

@@ -220,3 +220,26 @@ def test_config4_full_size_properties():
         o.push_ir(ir_h[c])
         want = np.stack([o.convolution(x_h[b, c]) for b in range(blocks)])
         assert_parity(y_h[:, c], want, tol=CTOL, what="channel %d" % c)
+
+
+@pytest.mark.parametrize("pts,nparts,channels,blocks,tv", [(512, 5, 130, 7, False), (1024, 4, 128, 6, True),
+                                                          (2048, 3, 140, 5, False), (4096, 2, 128, 4, True)])
+def test_pconv_fused_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
+    """enough channels to select the one-launch-per-block kernel (forward + MAC + inverse per channel)"""
+    s = util.lcg_half(21 + pts, channels * (pts * nparts + 2 * pts * blocks))
+    ir = s[:channels * pts * nparts].reshape(channels, pts * nparts)
+    x1 = s[channels * pts * nparts:channels * (pts * nparts + pts * blocks)].reshape(channels, pts * blocks)
+    x2 = s[channels * (pts * nparts + pts * blocks):].reshape(channels, pts * blocks)
+    p = fa.Clpconv(0, pts * nparts, pts, channels=channels)
+    assert p.get_cl_err() == 0
+    if not tv:
+        assert p.push_ir(ir) == 0
+    out = _run(p, blocks, pts, x1, x2 if tv else None)
+    for c in (0, 1, channels // 2, channels - 1):
+        o = oracle.Pconv(pts * nparts, pts)
+        if not tv:
+            o.push_ir(ir[c])
+        want = np.concatenate([o.convolution(x1[c, b * pts:(b + 1) * pts], x2[c, b * pts:(b + 1) * pts] if tv else None)
+                               for b in range(blocks)])
+        assert_parity(out[c], want, tol=CTOL, what="channel %d" % c)
+    assert (p.wp, p.wp2) == (blocks % nparts, (nparts - 1 - (blocks if tv else 0)) % nparts)
