@@ -75,6 +75,23 @@ void fill_w2(std::vector<cpx> &v, int m, float sign) {
   }
 }
 
+// host tables of the four-step kernel: [half N1 | half N2 | lo: W_n^k, k < 2^loglo | hi: W_n^(k 2^loglo)]
+void fill_fourstep_tables(std::vector<cpx> &all, int logn) {
+  int l1, l2, llo;
+  fourstep_split(logn, &l1, &l2, &llo);
+  const int n = 1 << logn, n1 = 1 << l1, n2 = 1 << l2, lo = 1 << llo, hi = n >> llo;
+  std::vector<cpx> part;
+  all.clear();
+  fill_twiddle(part, n1 / 2, n1, 1, -1.f);
+  all.insert(all.end(), part.begin(), part.begin() + n1 / 2);
+  fill_twiddle(part, n2 / 2, n2, 1, -1.f);
+  all.insert(all.end(), part.begin(), part.begin() + n2 / 2);
+  fill_twiddle(part, lo, n, 1, -1.f);
+  all.insert(all.end(), part.begin(), part.begin() + lo);
+  fill_twiddle(part, hi, n, lo, -1.f);
+  all.insert(all.end(), part.begin(), part.begin() + hi);
+}
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -290,18 +307,8 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     if ((e = upload(p->half, h.data(), sizeof(cpx) * h.size()))) return e;
     p->tabs.half = (const cpx *)p->half.p;
   } else {
-    int l1, l2, llo;
-    fourstep_split(p->logn, &l1, &l2, &llo);
-    int n1 = 1 << l1, n2 = 1 << l2, lo = 1 << llo, hi = n >> llo;
-    std::vector<cpx> all, part;
-    fill_twiddle(part, n1 / 2, n1, 1, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + n1 / 2);
-    fill_twiddle(part, n2 / 2, n2, 1, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + n2 / 2);
-    fill_twiddle(part, lo, n, 1, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + lo);
-    fill_twiddle(part, hi, n, lo, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + hi);
+    std::vector<cpx> all;
+    fill_fourstep_tables(all, p->logn);
     if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
     p->tabs.four = (const cpx *)p->four.p;
     size_t sbytes = (size_t)fourstep_grid(p->logn, p->variant, p->di) * n * sizeof(cpx);
@@ -503,18 +510,9 @@ static int pconv_setup(clfa_pconv *p, int device, int cvs, int pts, int channels
   fill_w2(h, pts, 1.f);            // cl_conv.cpp:282-287
   if ((e = upload(p->w2i, h.data(), sizeof(cpx) * pts))) return e;
   if (p->g.logb > kLdsMaxLog) {
-    int l1, l2, llo;
-    fourstep_split(p->g.logb, &l1, &l2, &llo);
-    const int n = pts, n1 = 1 << l1, n2 = 1 << l2, lo = 1 << llo, hi = n >> llo;
-    std::vector<cpx> all, part;
-    fill_twiddle(part, n1 / 2, n1, 1, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + n1 / 2);
-    fill_twiddle(part, n2 / 2, n2, 1, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + n2 / 2);
-    fill_twiddle(part, lo, n, 1, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + lo);
-    fill_twiddle(part, hi, n, lo, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + hi);
+    const int n = pts;
+    std::vector<cpx> all;
+    fill_fourstep_tables(all, p->g.logb);
     if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
     p->big.four = (const cpx *)p->four.p;
     if ((e = p->scratch.ensure((size_t)fourstep_grid(p->g.logb, 0, p->di) * n * sizeof(cpx)))) return e;

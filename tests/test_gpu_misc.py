@@ -103,3 +103,41 @@ def test_bench_two_rank_rehearsal():
     # whole-job value = samples of BOTH ranks over the max time
     expect = 2 * 256 * 65536 * 4 / (r["ms_per_step"] * 4 * 1e-3) / 1e9
     assert abs(r["value"] - expect) / expect < 1e-6
+
+
+def test_device_entry_points_capture_into_a_hip_graph():
+    """the launch path neither allocates nor synchronises, so a sequence of transforms on a caller
+    stream can be captured once and replayed (hipGraph via torch.cuda.CUDAGraph)"""
+    import torch
+    n, batch = 4096, 64
+    size, rbatch = 2048, 32
+    d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
+    r = torch.rand((rbatch, size), device="cuda") * 2 - 1
+    big = torch.rand((8, 65536, 2), device="cuda") * 2 - 1
+    x0, r0, b0 = d.clone(), r.clone(), big.clone()
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    rf = fa.Clrfft(0, size, True)
+    bf = fa.Clcfft(0, 65536, True)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):           # warm up outside the capture (module load, occupancy query)
+        for p, buf, nb in ((f, d, batch), (i, d, batch), (rf, r, rbatch), (bf, big, 8)):
+            assert p.exec_device(buf, nb, side.cuda_stream) == 0
+    side.synchronize()
+    d.copy_(x0); r.copy_(r0); big.copy_(b0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s = torch.cuda.current_stream().cuda_stream
+        assert f.exec_device(d, batch, s) == 0
+        assert i.exec_device(d, batch, s) == 0      # back to the input
+        assert f.exec_device(d, batch, s) == 0
+        assert rf.exec_device(r, rbatch, s) == 0
+        assert bf.exec_device(big, 8, s) == 0
+    for _ in range(3):                               # replays see fresh inputs
+        d.copy_(x0); r.copy_(r0); big.copy_(b0)
+        g.replay()
+    torch.cuda.synchronize()
+    y = d.cpu().numpy().view(np.complex64).reshape(batch, n)
+    assert_parity(y, oracle.cfft(x0.cpu().numpy().view(np.complex64).reshape(batch, n), True), what="c2c in graph")
+    assert_parity(r.cpu().numpy().view(np.complex64), oracle.rfft_forward(r0.cpu().numpy()), what="r2c in graph")
+    assert_parity(big.cpu().numpy().view(np.complex64).reshape(8, 65536),
+                  oracle.cfft(b0.cpu().numpy().view(np.complex64).reshape(8, 65536), True), what="N=65536 in graph")
