@@ -12,6 +12,10 @@
 //                conv / iconv / reorder kernels.
 #include <cstdlib>
 
+#ifndef CLFA_4STEP_OPAQUE
+#define CLFA_4STEP_OPAQUE 1
+#endif
+
 #include "fft_wg.hpp"
 
 namespace clfa {
@@ -396,6 +400,7 @@ template <int LOGN, bool FWD, bool SCALE, int NSLICE, bool NT, bool PF = false>
 __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ data, cpx *__restrict__ scratch,
                                                            const cpx *__restrict__ tabs_g, long batch) {
   using G = FourGeom<LOGN>;
+  constexpr bool OPQ = CLFA_4STEP_OPAQUE;
   __shared__ cpx s_tabs[G::TABS];
   __shared__ cpx s_x[NSLICE * G::SL];
   const int tid = threadIdx.x;
@@ -411,11 +416,19 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
     cpx *x = data + b * (long)G::N;
     if constexpr (!PF) {
 #pragma unroll 1
-      for (int cb = slice; cb < G::NCB; cb += NSLICE) four_phase1<LOGN, FWD, NT ? 1 : 0>(x, mid, cb, l, tab1, tlo, thi, sx);
+      for (int cb = slice; cb < G::NCB; cb += NSLICE) {
+        int lo_ = l;   // opaque per iteration: keeps hipcc from hoisting (and spilling) every LDS / global offset
+        if (OPQ) asm volatile("" : "+v"(lo_));
+        four_phase1<LOGN, FWD, NT ? 1 : 0>(x, mid, cb, lo_, tab1, tlo, thi, sx);
+      }
       // the workgroup re-reads what it has just stored: workgroup-scope release/acquire
       __syncthreads();
 #pragma unroll 1
-      for (int rb = slice; rb < G::NRB; rb += NSLICE) four_phase2<LOGN, FWD, SCALE, NT ? 1 : 0>(mid, x, rb, l, tab2, sx);
+      for (int rb = slice; rb < G::NRB; rb += NSLICE) {
+        int lo_ = l;
+        if (OPQ) asm volatile("" : "+v"(lo_));
+        four_phase2<LOGN, FWD, SCALE, NT ? 1 : 0>(mid, x, rb, lo_, tab2, sx);
+      }
       __syncthreads();
     } else {
       // software-prefetched form: the next block's loads fly behind the current block's passes.
@@ -490,7 +503,8 @@ struct FourVariant {
 };
 static FourVariant four_variant(int variant) {
   // {slices of 256 lanes per workgroup, non-temporal streaming, workgroups per CU}.
-  // Measured on MI355X, N = 65536 x 4096 (profiles/): 0 is the fastest (1.45 ms).
+  // Measured on MI355X, N = 65536 x 4096, interleaved in one process (tools/ab_variants.py): all
+  // shapes land in 1.40-1.56 ms and differ by less than the process-to-process spread (~7 %).
   switch (variant) {
     case 1: return {4, false, 1, false};
     case 2: return {2, false, 2, false};
@@ -504,7 +518,8 @@ static FourVariant four_variant(int variant) {
     case 11: return {1, true, 2, true};
     case 12: return {2, true, 1, true};
     case 13: return {2, true, 2, true};
-    default: return {1, true, 2, false};  // 0
+    case 15: return {1, true, 2, false};
+    default: return {2, true, 2, false};  // 0: 168 VGPRs, no spills, 256 MiB of scratch
   }
 }
 
