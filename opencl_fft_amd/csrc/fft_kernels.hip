@@ -438,28 +438,40 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       four_load1<LOGN, NT ? 1 : 0>(v, x, slice, l);
 #pragma unroll 1
       for (int cb = slice; cb + NSLICE < G::NCB; cb += NSLICE) {
-        four_load1<LOGN, NT ? 1 : 0>(vn, x, cb + NSLICE, l);
-        four_body1<LOGN, FWD>(v, mid, cb, l, tab1, tlo, thi, sx);
+        int lo_ = l;   // opaque per iteration (see above)
+        asm volatile("" : "+v"(lo_));
+        four_load1<LOGN, NT ? 1 : 0>(vn, x, cb + NSLICE, lo_);
+        four_body1<LOGN, FWD>(v, mid, cb, lo_, tab1, tlo, thi, sx);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
           v[e] = vn[e];
         }
       }
-      four_body1<LOGN, FWD>(v, mid, G::NCB - NSLICE + slice, l, tab1, tlo, thi, sx);
+      {
+        int lo_ = l;
+        asm volatile("" : "+v"(lo_));
+        four_body1<LOGN, FWD>(v, mid, G::NCB - NSLICE + slice, lo_, tab1, tlo, thi, sx);
+      }
       __syncthreads();
       four_load2<LOGN, false>(v, mid, slice, l);
 #pragma unroll 1
       for (int rb = slice; rb + NSLICE < G::NRB; rb += NSLICE) {
-        four_load2<LOGN, false>(vn, mid, rb + NSLICE, l);
-        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, rb, l, tab2, sx);
+        int lo_ = l;
+        asm volatile("" : "+v"(lo_));
+        four_load2<LOGN, false>(vn, mid, rb + NSLICE, lo_);
+        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, rb, lo_, tab2, sx);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
           v[e] = vn[e];
         }
       }
-      four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, G::NRB - NSLICE + slice, l, tab2, sx);
+      {
+        int lo_ = l;
+        asm volatile("" : "+v"(lo_));
+        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, G::NRB - NSLICE + slice, lo_, tab2, sx);
+      }
       __syncthreads();
     }
   }
@@ -503,8 +515,9 @@ struct FourVariant {
 };
 static FourVariant four_variant(int variant) {
   // {slices of 256 lanes per workgroup, non-temporal streaming, workgroups per CU}.
-  // Measured on MI355X, N = 65536 x 4096, interleaved in one process (tools/ab_variants.py): all
-  // shapes land in 1.40-1.56 ms and differ by less than the process-to-process spread (~7 %).
+  // Measured on MI355X, N = 65536 x 4096, interleaved in one process (tools/ab_variants.py): the
+  // prefetching shapes (0 = 12, 13) run 1.32-1.37 ms, the others 1.40-1.56 ms; the process-to-process
+  // spread is ~5 %.
   switch (variant) {
     case 1: return {4, false, 1, false};
     case 2: return {2, false, 2, false};
@@ -519,7 +532,10 @@ static FourVariant four_variant(int variant) {
     case 12: return {2, true, 1, true};
     case 13: return {2, true, 2, true};
     case 15: return {1, true, 2, false};
-    default: return {2, true, 2, false};  // 0: 168 VGPRs, no spills, 256 MiB of scratch
+    case 16: return {1, true, 1, true};
+    case 17: return {4, true, 1, true};
+    case 18: return {2, true, 2, false};
+    default: return {2, true, 1, true};  // 0: software prefetch, one workgroup per CU, 128 MiB of scratch
   }
 }
 
@@ -555,7 +571,7 @@ static hipError_t launch_4step_v(int variant, cpx *data, cpx *scratch, const Fft
     return hipGetLastError();                                                                               \
   }
   CLFA_V(4, true, false) CLFA_V(4, false, false) CLFA_V(2, false, false) CLFA_V(2, true, false)
-  CLFA_V(1, false, false) CLFA_V(1, true, false) CLFA_V(1, true, true) CLFA_V(2, true, true)
+  CLFA_V(1, false, false) CLFA_V(1, true, false) CLFA_V(1, true, true) CLFA_V(2, true, true) CLFA_V(4, true, true)
 #undef CLFA_V
   return hipErrorInvalidValue;
 }

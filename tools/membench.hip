@@ -94,6 +94,43 @@ __global__ __launch_bounds__(THREADS) void k_twophase(v4 *out, const v4 *in, v4 
   }
 }
 
+// the FFT kernel's exact global access shape: 8 bytes per lane, 16 lanes per 128-byte row segment,
+// rows 2 KiB apart (column block in -> row-major scratch; scratch rows -> column block out)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_twophase8(unsigned long long *out, const unsigned long long *in,
+                                                   unsigned long long *scratch, int chunks) {
+  const int W = 65536;   // 8-byte words per 512 KiB chunk
+  unsigned long long *slot = scratch + (size_t)blockIdx.x * W;
+  const int col = threadIdx.x & 15, tf = threadIdx.x >> 4;
+  for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const unsigned long long *src = in + (size_t)c * W;
+    unsigned long long *dst = out + (size_t)c * W;
+    for (int cb = 0; cb < 16; cb++) {      // phase 1: column block cb (rows tf + 16 e) -> scratch, same places
+      unsigned long long r[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const unsigned long long *p = src + (tf + 16 * e) * 256 + cb * 16 + col;
+        r[e] = NT ? __builtin_nontemporal_load(p) : *p;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) slot[(tf + 16 * e) * 256 + cb * 16 + col] = r[e];
+    }
+    __syncthreads();
+    for (int rb = 0; rb < 16; rb++) {      // phase 2: row block rb contiguous -> column block rb of out
+      unsigned long long r[16];
+      const int t2 = threadIdx.x & 15, row = threadIdx.x >> 4;
+#pragma unroll
+      for (int e = 0; e < 16; e++) r[e] = slot[(rb * 16 + row) * 256 + t2 + 16 * e];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        unsigned long long *p = dst + (tf + 16 * e) * 256 + rb * 16 + col;
+        if (NT) __builtin_nontemporal_store(r[e], p); else *p = r[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <class F> static float timeit(F f, int iters = 5) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
@@ -163,6 +200,13 @@ int main() {
   TP(1024, 8, true, true, 256)
   TP(512, 8, true, true, 512)
   TP(256, 8, true, true, 1024)
+  printf("== two-phase emulation with the FFT kernel's own access shape (8 B per lane, 128-B segments)\n");
+  for (int G : {512, 1024}) {
+    float ms = timeit([&] { k_twophase8<true><<<G, 256>>>((unsigned long long *)b, (const unsigned long long *)a, (unsigned long long *)scratch, 4096); });
+    printf("8B lanes nt 1 grid %4d : %.3f ms  alg %.2f TB/s\n", G, ms, 2.0 * big / ms / 1e9);
+    ms = timeit([&] { k_twophase8<false><<<G, 256>>>((unsigned long long *)b, (const unsigned long long *)a, (unsigned long long *)scratch, 4096); });
+    printf("8B lanes nt 0 grid %4d : %.3f ms  alg %.2f TB/s\n", G, ms, 2.0 * big / ms / 1e9);
+  }
   printf("== two-phase emulation with L2-resident scratch: chunks of 32 KiB / 64 KiB / 128 KiB\n");
 #define TPC(THREADS, UNR, NT, G, CHKB)                                                                     \
   {                                                                                                          \
