@@ -374,7 +374,7 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
 }
 
 int clfa_fft_set_variant(clfa_fft *p, int variant) {
-  if (!p || variant < 0 || variant > 18) return CLFA_INVALID_VALUE;
+  if (!p || variant < 0 || variant > kVariantMax) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   p->variant = variant;
   if (p->logn > kLdsMaxLog) {

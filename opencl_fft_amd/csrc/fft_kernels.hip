@@ -514,27 +514,17 @@ struct FourVariant {
   bool pf;   // software prefetch of the next column / row block
 };
 static FourVariant four_variant(int variant) {
-  // {slices of 256 lanes per workgroup, non-temporal streaming, workgroups per CU}.
+  // {slices of 256 lanes per workgroup, non-temporal streaming, workgroups per CU, software prefetch}.
   // Measured on MI355X, N = 65536 x 4096, interleaved in one process (tools/ab_variants.py): the
-  // prefetching shapes (0 = 12, 13) run 1.32-1.37 ms, the others 1.40-1.56 ms; the process-to-process
-  // spread is ~5 %.
+  // prefetching shapes (0, 1) run 1.32-1.37 ms, the others 1.40-1.56 ms; the process-to-process
+  // spread is ~5 %.  7 and 8 are the XCD-cooperative kernels (kVariantCoop, kVariantCoop2).
   switch (variant) {
-    case 1: return {4, false, 1, false};
-    case 2: return {2, false, 2, false};
-    case 3: return {4, true, 1, false};
-    case 4: return {1, false, 4, false};
-    case 5: return {1, false, 2, false};
-    case 6: return {2, false, 1, false};
-    case 8: return {1, true, 4, false};
-    case 9: return {2, true, 2, false};
-    case 10: return {1, true, 2, false};
-    case 11: return {1, true, 2, true};
-    case 12: return {2, true, 1, true};
-    case 13: return {2, true, 2, true};
-    case 15: return {1, true, 2, false};
-    case 16: return {1, true, 1, true};
-    case 17: return {4, true, 1, true};
-    case 18: return {2, true, 2, false};
+    case 1: return {2, true, 2, true};
+    case 2: return {1, true, 2, true};
+    case 3: return {2, true, 2, false};
+    case 4: return {1, true, 2, false};
+    case 5: return {4, true, 1, false};
+    case 6: return {2, false, 2, false};
     default: return {2, true, 1, true};  // 0: software prefetch, one workgroup per CU, 128 MiB of scratch
   }
 }
@@ -570,8 +560,8 @@ static hipError_t launch_4step_v(int variant, cpx *data, cpx *scratch, const Fft
                        scratch, t.four, batch);                                                             \
     return hipGetLastError();                                                                               \
   }
-  CLFA_V(4, true, false) CLFA_V(4, false, false) CLFA_V(2, false, false) CLFA_V(2, true, false)
-  CLFA_V(1, false, false) CLFA_V(1, true, false) CLFA_V(1, true, true) CLFA_V(2, true, true) CLFA_V(4, true, true)
+  CLFA_V(2, true, true) CLFA_V(1, true, true) CLFA_V(2, true, false) CLFA_V(1, true, false) CLFA_V(4, true, false)
+  CLFA_V(2, false, false)
 #undef CLFA_V
   return hipErrorInvalidValue;
 }
@@ -811,7 +801,7 @@ __global__ __launch_bounds__(256, 3) void k_fft_coop(cpx *__restrict__ data, cpx
 }
 
 // ---------------------------------------------------------------------------------
-// readiness-driven cooperative kernel (variant 14)
+// readiness-driven cooperative kernel (variant 8)
 // ---------------------------------------------------------------------------------
 // Same per-XCD structures as k_fft_coop, different scheduling: instead of one queue in a
 // fixed order, each XCD keeps

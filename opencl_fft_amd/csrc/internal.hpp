@@ -47,8 +47,9 @@ size_t coop_scratch_bytes(int logn);
 hipError_t launch_fft_coop(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
                            long batch, const DeviceInfo &di, hipStream_t s);
 hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s);
-// readiness-driven cooperative kernel (variant 14)
-constexpr int kVariantCoop2 = 14;
+// readiness-driven cooperative kernel (variant 8)
+constexpr int kVariantCoop2 = 8;
+constexpr int kVariantMax = 8;
 size_t coop2_ctl_bytes();
 hipError_t launch_fft_coop2(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
                             long batch, const DeviceInfo &di, hipStream_t s);

@@ -134,7 +134,7 @@ def test_cfft_device_resident_batch():
     assert np.max(np.abs(e_out / e_in - 1)) < 1e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_cfft_large_kernel_variants(variant):
     n, batch = 65536, 5
     x = util.lcg_complex(31 + variant, n * batch).reshape(batch, n)
@@ -249,9 +249,9 @@ def test_config3_full_size_roundtrip():
 
 
 @pytest.mark.parametrize("n,batch", [(16384, 1), (16384, 37), (32768, 19), (65536, 1), (65536, 2), (65536, 23), (65536, 300)])
-@pytest.mark.parametrize("variant", [7, 14])
+@pytest.mark.parametrize("variant", [7, 8])
 def test_cfft_cooperative_kernel(n, batch, variant):
-    """XCD-cooperative large-N kernels (7: ordered queue, 14: readiness-driven): any batch, both directions"""
+    """XCD-cooperative large-N kernels (7: ordered queue, 8: readiness-driven): any batch, both directions"""
     x = util.lcg_complex(77 + batch, n * batch).reshape(batch, n)
     for fwd in (True, False):
         plan = fa.Clcfft(0, n, fwd)

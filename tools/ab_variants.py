@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 import torch
 import opencl_fft_amd as fa
 n, batch = 65536, 4096
-variants = [int(a) for a in sys.argv[1:]] or [0, 9]
+variants = [int(a) for a in sys.argv[1:]] or [0, 3]
 rounds, per = 7, 6
 d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
 plans = {}
