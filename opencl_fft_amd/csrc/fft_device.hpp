@@ -231,4 +231,43 @@ template <int LOGN, int LOGE, class Ld> CLFA_HD void pass_gather(cpx (&v)[1 << L
   for (int e = 0; e < E; e++) v[e] = ld(tid + T * e);
 }
 
+// The same two operations on a buffer in the padded layout lds_pad(), with the padding
+// arithmetic hoisted: lds_pad(b + k*s) == lds_pad(b) + k*(s + s/16) whenever s is a multiple
+// of 16, and == lds_pad(b) + k*s when b is a multiple of 16 and k*s < 16.  Every position is then
+// `one lane-dependent base + compile-time constant`, which the compiler folds into the
+// ds_read/ds_write offset field instead of a shift and an add per element.
+template <int LOGN, int LOGE, int LOGNS>
+CLFA_HD void pass_scatter_padded(const cpx (&v)[1 << LOGE], int tid, cpx *xb) {
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
+  constexpr int E = 1 << LOGE, R = 1 << LOGR, U = E / R, T = 1 << (LOGN - LOGE), NS = 1 << LOGNS;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int j = tid + u * T;
+    const int base = ((j >> LOGNS) << (LOGNS + LOGR)) + (j & (NS - 1));
+    if constexpr (NS >= 16) {
+      cpx *p = xb + lds_pad(base);
+#pragma unroll
+      for (int q = 0; q < R; q++) p[q * (NS + NS / 16)] = v[u + U * q];
+    } else if constexpr (NS == 1 && R == 16) {
+      cpx *p = xb + lds_pad(base);   // base = 16 j
+#pragma unroll
+      for (int q = 0; q < R; q++) p[q] = v[u + U * q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < R; q++) xb[lds_pad(base + (q << LOGNS))] = v[u + U * q];
+    }
+  }
+}
+template <int LOGN, int LOGE> CLFA_HD void pass_gather_padded(cpx (&v)[1 << LOGE], int tid, const cpx *xb) {
+  constexpr int E = 1 << LOGE, T = 1 << (LOGN - LOGE);
+  if constexpr (T >= 16) {
+    const cpx *p = xb + lds_pad(tid);
+#pragma unroll
+    for (int e = 0; e < E; e++) v[e] = p[e * (T + T / 16)];
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; e++) v[e] = xb[lds_pad(tid + T * e)];
+  }
+}
+
 }  // namespace clfa

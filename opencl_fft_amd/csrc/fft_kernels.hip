@@ -137,7 +137,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
         }
       }
       __syncthreads();
-      pass_gather<LOGN, G::LOGE>(v, t, [&](int p) { return xb[lds_pad(p)]; });
+      pass_gather_padded<LOGN, G::LOGE>(v, t, xb);
     }
 
     if constexpr (TWO) wg_passes<LOGN, G::LOGE, 0, FWD>(v, t, tab2, xb);
@@ -356,7 +356,7 @@ __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, 
     pass_compute<G::LOGN2, 4, 0, FWD>(v, tf, tab2);
     __syncthreads();
     cpx *xr = sx + row * G::S2;
-    pass_scatter<G::LOGN2, 4, 0>(v, tf, [&](int q, cpx val) { xr[lds_pad(q)] = val; });
+    pass_scatter_padded<G::LOGN2, 4, 0>(v, tf, xr);
     __syncthreads();
     // every lane has consumed its loads from the scratch: the slot may be reused
     if (read_done != nullptr && l == 0)
@@ -366,7 +366,7 @@ __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, 
   // store below is contiguous across lanes
   const int row = l % G::R2, tf = l / G::R2;
   const cpx *xr = sx + row * G::S2;
-  pass_gather<G::LOGN2, 4>(v, tf, [&](int q) { return xr[lds_pad(q)]; });
+  pass_gather_padded<G::LOGN2, 4>(v, tf, xr);
   pass_compute<G::LOGN2, 4, 4, FWD>(v, tf, tab2);
   const int k1 = rb * G::R2 + row;
 #pragma unroll

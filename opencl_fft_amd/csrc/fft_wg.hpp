@@ -11,9 +11,9 @@ __device__ __forceinline__ void wg_passes(cpx (&v)[1 << LOGE], int t, const Tab 
   constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
   if constexpr (LOGNS + LOGR < LOGN) {
     __syncthreads();  // everybody is done reading the previous exchange
-    pass_scatter<LOGN, LOGE, LOGNS>(v, t, [&](int p, cpx val) { xb[lds_pad(p)] = val; });
+    pass_scatter_padded<LOGN, LOGE, LOGNS>(v, t, xb);
     __syncthreads();
-    pass_gather<LOGN, LOGE>(v, t, [&](int p) { return xb[lds_pad(p)]; });
+    pass_gather_padded<LOGN, LOGE>(v, t, xb);
     wg_passes<LOGN, LOGE, LOGNS + LOGR, FWD>(v, t, tab, xb);
   }
 }
