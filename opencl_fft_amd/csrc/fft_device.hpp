@@ -150,8 +150,11 @@ template <int LOGR, int U, int E, bool FWD> CLFA_HD void dft(cpx (&v)[E], int u)
 // ---- Stockham pass schedule ---------------------------------------------------
 
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
-// radix (log2) of the pass that starts with sub-transform length 2^LOGNS
+// radix (log2) of the pass that starts with sub-transform length 2^LOGNS: 2^LOGE, except the last
+// ("remainder") pass, which starts at 2^pass_last_logns and has radix 2^pass_rem_logr
 constexpr int pass_logr(int LOGN, int LOGE, int LOGNS) { return cmin(LOGE, LOGN - LOGNS); }
+constexpr int pass_rem_logr(int LOGN, int LOGE) { return (LOGN - 1) % LOGE + 1; }
+constexpr int pass_last_logns(int LOGN, int LOGE) { return LOGN - pass_rem_logr(LOGN, LOGE); }
 
 // padded LDS position: one pad element per 16 keeps the stride-16 scatter of
 // the first exchange and the contiguous gathers conflict-free (ds_*_b64)
@@ -267,6 +270,278 @@ template <int LOGN, int LOGE> CLFA_HD void pass_gather_padded(cpx (&v)[1 << LOGE
   } else {
 #pragma unroll
     for (int e = 0; e < E; e++) v[e] = xb[lds_pad(tid + T * e)];
+  }
+}
+
+// ---- the transposed chain (decimation in frequency) ---------------------------------------------
+// The DFT matrix is symmetric, so the transposes of the passes above, run in the opposite order
+// (remainder pass FIRST), compute the same transform.  Transposed pass (NS, R): butterfly
+// j = tid + u*T gathers its inputs from where the pass above scatters to, runs the R-point DFT and
+// multiplies OUTPUT q by W_(NS*R)^((j mod NS) * q); output q belongs at position j + (n/R)*q, so a
+// lane owns positions tid + T*e on EXIT from every pass and the final stores are coalesced.  Same
+// butterflies, same twiddle count, same LDS patterns (reads and writes swapped).  It exists for the
+// inverse packed-real transform, whose pair map sits on the INPUT side and needs the small-radix
+// pass there (pass_first_paired below).
+template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
+CLFA_HD void dif_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
+  constexpr int E = 1 << LOGE, R = 1 << LOGR, U = E / R, T = 1 << (LOGN - LOGE), NS = 1 << LOGNS;
+#pragma unroll
+  for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
+  if constexpr (LOGNS > 0) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int jm = (tid + u * T) & (NS - 1);
+#pragma unroll
+      for (int q = 1; q < R; q++) {
+        int k = (jm * q) << (LOGN - LOGNS - LOGR);
+        v[u + U * q] = cmul(v[u + U * q], tw_lookup<LOGN, FWD>(tab, k));
+      }
+    }
+  }
+}
+// inputs of the transposed pass (NS, R) from the padded buffer (mirror of pass_scatter_padded)
+template <int LOGN, int LOGE, int LOGNS>
+CLFA_HD void dif_gather_padded(cpx (&v)[1 << LOGE], int tid, const cpx *xb) {
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
+  constexpr int E = 1 << LOGE, R = 1 << LOGR, U = E / R, T = 1 << (LOGN - LOGE), NS = 1 << LOGNS;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int j = tid + u * T;
+    const int base = ((j >> LOGNS) << (LOGNS + LOGR)) + (j & (NS - 1));
+    if constexpr (NS >= 16) {
+      const cpx *p = xb + lds_pad(base);
+#pragma unroll
+      for (int t = 0; t < R; t++) v[u + U * t] = p[t * (NS + NS / 16)];
+    } else if constexpr (NS == 1 && R == 16) {
+      const cpx *p = xb + lds_pad(base);   // base = 16 j
+#pragma unroll
+      for (int t = 0; t < R; t++) v[u + U * t] = p[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < R; t++) v[u + U * t] = xb[lds_pad(base + (t << LOGNS))];
+    }
+  }
+}
+// outputs to the lane-owned positions tid + T*e (mirror of pass_gather_padded)
+template <int LOGN, int LOGE> CLFA_HD void dif_scatter_padded(const cpx (&v)[1 << LOGE], int tid, cpx *xb) {
+  constexpr int E = 1 << LOGE, T = 1 << (LOGN - LOGE);
+  if constexpr (T >= 16) {
+    cpx *p = xb + lds_pad(tid);
+#pragma unroll
+    for (int e = 0; e < E; e++) p[e * (T + T / 16)] = v[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; e++) xb[lds_pad(tid + T * e)] = v[e];
+  }
+}
+
+// ---- packed real transforms: the reference's pair maps, and passes that pair in registers ------
+
+// reference conv kernel, cl_fft.cpp:178-191 (pair i, M-i; bin M/2 not visited)
+CLFA_HD void r2c_pair(cpx ci, cpx cjraw, cpx w, cpx &oi, cpx &oj) {
+  cpx cj = cconj(cjraw);
+  cpx e = cscale(cadd(ci, cj), .5f);
+  cpx d = csub(cj, ci);
+  cpx o = cscale(mk(-d.y, d.x), .5f);
+  cpx p = cmul(w, o);
+  oi = cadd(e, p);
+  oj = cconj(csub(e, p));
+}
+// reference iconv kernel, cl_fft.cpp:192-205
+CLFA_HD void c2r_pair(cpx ci, cpx cjraw, cpx w, cpx &oi, cpx &oj) {
+  cpx cj = cconj(cjraw);
+  cpx e = cscale(cadd(ci, cj), .5f);
+  cpx d = csub(ci, cj);
+  cpx o = cscale(mk(-d.y, d.x), .5f);
+  cpx p = cmul(w, o);
+  oi = cadd(e, p);
+  oj = cconj(csub(e, p));
+}
+
+// The pair maps combine bins i and M-i of an M-point complex transform.  In the remainder pass
+// (radix R < 2^LOGE, U = E/R >= 2 butterflies per lane, NB = M/R butterflies in all) butterfly j
+// touches positions j + NB*t, and M - (j + NB*t) = (NB - j) + NB*(R-1-t): a lane that takes
+// butterflies j AND NB - j holds both halves of R pairs in its own registers, so the LDS round
+// trip that the pair map otherwise needs (write every bin, barrier, read the partners) disappears.
+// Lane `tid` takes j = tid + u*T (u < U/2, so j < NB/2) in register slots u + U*t and NB - j in
+// slots u + U/2 + U*t.  Butterflies 0 and NB/2 pair within themselves: lane 0 takes both as its
+// u = 0 pair and permutes its registers so that the same straight-line pair code applies.
+// Pair (u, q) is handed out as (k = u*R + q, i = the reference's loop index, partner M - i, or
+// M/2 for i = 0: the packed DC/Nyquist bin and the bin the reference never visits).
+constexpr bool pair_ok(int LOGN, int LOGE) { return LOGN > LOGE && pass_rem_logr(LOGN, LOGE) < LOGE; }
+
+template <int LOGN, int LOGE> CLFA_HD int pair_index(int tid, int u, int q) {
+  constexpr int LOGR = pass_rem_logr(LOGN, LOGE), R = 1 << LOGR, T = 1 << (LOGN - LOGE), NB = 1 << (LOGN - LOGR);
+  const int j = tid + u * T;
+  if (j == 0) return q < R / 2 ? NB * q : NB / 2 + NB * (q - R / 2);
+  return q < R / 2 ? j + NB * q : NB * (R - q) - j;
+}
+
+// lane 0, u = 0: slots as the straight-line pair code expects them <- butterflies 0 (m) and NB/2 (p)
+template <int R> CLFA_HD void pair_perm_lane0(bool lane0, cpx (&m)[R], cpx (&p)[R]) {
+  cpx nm[R], np[R];
+  nm[0] = m[0];
+  np[R - 1] = m[R / 2];
+#pragma unroll
+  for (int q = 1; q < R / 2; q++) {
+    nm[q] = m[q];
+    np[R - 1 - q] = m[R - q];
+  }
+#pragma unroll
+  for (int q = 0; q < R / 2; q++) {
+    np[R / 2 - 1 - q] = p[q];
+    nm[R / 2 + q] = p[R - 1 - q];
+  }
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    m[q] = lane0 ? nm[q] : m[q];
+    p[q] = lane0 ? np[q] : p[q];
+  }
+}
+// and back: butterflies 0 (m) and NB/2 (p) <- slots as the pair code fills them
+template <int R> CLFA_HD void pair_unperm_lane0(bool lane0, cpx (&m)[R], cpx (&p)[R]) {
+  cpx am[R], ap[R];
+  am[0] = m[0];
+  am[R / 2] = p[R - 1];
+#pragma unroll
+  for (int q = 1; q < R / 2; q++) {
+    am[q] = m[q];
+    am[R - q] = p[R - 1 - q];
+  }
+#pragma unroll
+  for (int q = 0; q < R / 2; q++) {
+    ap[q] = p[R / 2 - 1 - q];
+    ap[R - 1 - q] = m[R / 2 + q];
+  }
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    m[q] = lane0 ? am[q] : m[q];
+    p[q] = lane0 ? ap[q] : p[q];
+  }
+}
+
+// Forward: the LAST (remainder) pass of an M-point transform, butterflies paired as above; gathers
+// from the padded exchange buffer.  Afterwards slot u + U*q holds Z[j + NB*q] and slot
+// u + U/2 + U*q holds Z[jp + NB*q], jp = NB - j (NB/2 for j = 0).
+template <int LOGN, int LOGE, bool FWD, class Tab>
+CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, const cpx *xb) {
+  static_assert(pair_ok(LOGN, LOGE), "needs a remainder pass with two butterflies per lane");
+  constexpr int LOGR = pass_rem_logr(LOGN, LOGE), R = 1 << LOGR, E = 1 << LOGE, U = E / R;
+  constexpr int T = 1 << (LOGN - LOGE), NB = 1 << (LOGN - LOGR);
+#pragma unroll
+  for (int u = 0; u < U / 2; u++) {
+    const int j = tid + u * T;
+    const int jp = j == 0 ? NB / 2 : NB - j;
+    if constexpr (NB >= 16) {   // lane base + constant (see pass_scatter_padded)
+      const cpx *pm = xb + lds_pad(j), *pp = xb + lds_pad(jp);
+#pragma unroll
+      for (int t = 0; t < R; t++) {
+        v[u + U * t] = pm[t * (NB + NB / 16)];
+        v[u + U / 2 + U * t] = pp[t * (NB + NB / 16)];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < R; t++) {
+        v[u + U * t] = xb[lds_pad(j + NB * t)];
+        v[u + U / 2 + U * t] = xb[lds_pad(jp + NB * t)];
+      }
+    }
+#pragma unroll
+    for (int t = 1; t < R; t++) {
+      v[u + U * t] = cmul(v[u + U * t], tw_lookup<LOGN, FWD>(tab, j * t));
+      v[u + U / 2 + U * t] = cmul(v[u + U / 2 + U * t], tw_lookup<LOGN, FWD>(tab, jp * t));
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
+}
+
+// ... and its pairs: f(k, i, Z[i], Z[M - i]) (for i = 0: Z[0], Z[M/2]), k = u*R + q
+template <int LOGN, int LOGE, class F> CLFA_HD void pairs_visit(const cpx (&v)[1 << LOGE], int tid, F f) {
+  constexpr int LOGR = pass_rem_logr(LOGN, LOGE), R = 1 << LOGR, E = 1 << LOGE, U = E / R;
+#pragma unroll
+  for (int u = 0; u < U / 2; u++) {
+    cpx m[R], p[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      m[q] = v[u + U * q];
+      p[q] = v[u + U / 2 + U * q];
+    }
+    if (u == 0) pair_perm_lane0<R>(tid == 0, m, p);
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int i = pair_index<LOGN, LOGE>(tid, u, q);
+      if (q < R / 2) f(u * R + q, i, m[q], p[R - 1 - q]);
+      else f(u * R + q, i, p[R - 1 - q], m[q]);
+    }
+  }
+}
+
+// Inverse: the FIRST pass of the transposed chain (the remainder pass, NS = NB).  oi[k] / oj[k] are
+// the pair map's results for positions i / M - i of pair k (pair_index); runs the radix-R butterflies
+// with their output twiddles and scatters to positions j + NB*q, jp + NB*q of the padded buffer.
+// Continue with dif_gather_padded / dif_compute at LOGNS = pass_last_logns - LOGE.
+template <int LOGN, int LOGE, bool FWD, class Tab>
+CLFA_HD void pass_first_paired(cpx (&v)[1 << LOGE], int tid, const cpx (&oi)[(1 << LOGE) / 2],
+                               const cpx (&oj)[(1 << LOGE) / 2], const Tab &tab) {
+  static_assert(pair_ok(LOGN, LOGE), "needs a remainder pass with two butterflies per lane");
+  constexpr int LOGR = pass_rem_logr(LOGN, LOGE), R = 1 << LOGR, E = 1 << LOGE, U = E / R;
+  constexpr int T = 1 << (LOGN - LOGE), NB = 1 << (LOGN - LOGR);
+#pragma unroll
+  for (int u = 0; u < U / 2; u++) {
+    cpx m[R], p[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      if (q < R / 2) {
+        m[q] = oi[u * R + q];
+        p[R - 1 - q] = oj[u * R + q];
+      } else {
+        p[R - 1 - q] = oi[u * R + q];
+        m[q] = oj[u * R + q];
+      }
+    }
+    if (u == 0) pair_unperm_lane0<R>(tid == 0, m, p);
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      v[u + U * q] = m[q];
+      v[u + U / 2 + U * q] = p[q];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
+#pragma unroll
+  for (int u = 0; u < U / 2; u++) {
+    const int j = tid + u * T;
+    const int jp = j == 0 ? NB / 2 : NB - j;
+#pragma unroll
+    for (int q = 1; q < R; q++) {
+      v[u + U * q] = cmul(v[u + U * q], tw_lookup<LOGN, FWD>(tab, j * q));
+      v[u + U / 2 + U * q] = cmul(v[u + U / 2 + U * q], tw_lookup<LOGN, FWD>(tab, jp * q));
+    }
+  }
+}
+template <int LOGN, int LOGE> CLFA_HD void pass_first_paired_scatter(const cpx (&v)[1 << LOGE], int tid, cpx *xb) {
+  constexpr int LOGR = pass_rem_logr(LOGN, LOGE), R = 1 << LOGR, E = 1 << LOGE, U = E / R;
+  constexpr int T = 1 << (LOGN - LOGE), NB = 1 << (LOGN - LOGR);
+#pragma unroll
+  for (int u = 0; u < U / 2; u++) {
+    const int j = tid + u * T;
+    const int jp = j == 0 ? NB / 2 : NB - j;
+    if constexpr (NB >= 16) {
+      cpx *pm = xb + lds_pad(j), *pp = xb + lds_pad(jp);
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        pm[q * (NB + NB / 16)] = v[u + U * q];
+        pp[q * (NB + NB / 16)] = v[u + U / 2 + U * q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        xb[lds_pad(j + NB * q)] = v[u + U * q];
+        xb[lds_pad(jp + NB * q)] = v[u + U / 2 + U * q];
+      }
+    }
   }
 }
 

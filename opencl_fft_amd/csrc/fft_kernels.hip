@@ -49,7 +49,11 @@ __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const c
   if constexpr (MODE == MODE_C2R) {
 #pragma unroll
     for (int k = 0; k < E / 2; k++) {
-      const int i = t + T * k;
+      int i = t + T * k;
+      if constexpr (pair_ok(LOGN, G::LOGE)) {   // pairs in the order pass_first_paired wants them
+        constexpr int R = 1 << pass_rem_logr(LOGN, G::LOGE);
+        i = pair_index<LOGN, G::LOGE>(t, k / R, k % R);
+      }
       v[2 * k] = ld_nt(x + i);
       v[2 * k + 1] = ld_nt(x + (i == 0 ? N / 2 : N - i));
     }
@@ -82,10 +86,17 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
 
   // pack / unpack twiddles of this lane's pairs are the same for every transform
   constexpr int NP = (MODE == MODE_C2C) ? 1 : (E / 2 > 0 ? E / 2 : 1);
+  // packed real transforms pair bins i, N-i inside the remainder pass when it has two butterflies
+  // per lane (fft_device.hpp, pass_last_paired / pass_first_paired): one LDS exchange less
+  constexpr bool PAIRED = MODE != MODE_C2C && pair_ok(LOGN, G::LOGE);
+  constexpr int RREM = 1 << pass_rem_logr(LOGN, G::LOGE);
   cpx w2r[NP];
   if constexpr (MODE != MODE_C2C) {
 #pragma unroll
-    for (int k = 0; k < NP; k++) w2r[k] = w2_g[t + T * k];
+    for (int k = 0; k < NP; k++) {
+      if constexpr (PAIRED) w2r[k] = w2_g[pair_index<LOGN, G::LOGE>(t, k / RREM, k % RREM)];
+      else w2r[k] = w2_g[t + T * k];
+    }
   }
   __syncthreads();
 
@@ -120,28 +131,51 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       const long bn = gn * FPW + f;
       lds_fft_load<LOGN, MODE>(vn, data + (bn < batch ? bn : batch - 1) * (long)N, t);
     }
-    if constexpr (MODE == MODE_C2R) {
-      // fused reference `iconv` (cl_fft.cpp:192-205) on the way in
-      __syncthreads();
+    if constexpr (MODE == MODE_C2R && PAIRED) {
+      // fused reference `iconv` (cl_fft.cpp:192-205) in registers, then the transposed pass chain
+      cpx oi[E / 2], oj[E / 2];
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {
-        const int i = t + T * k;
-        if (i == 0) {
-          xb[0] = mk(v[0].x + v[0].y, v[0].x - v[0].y);
-          xb[lds_pad(N / 2)] = v[1];
-        } else {
-          cpx oi, oj;
-          c2r_pair(v[2 * k], v[2 * k + 1], w2r[k], oi, oj);
-          xb[lds_pad(i)] = oi;
-          xb[lds_pad(N - i)] = oj;
+        const int i = pair_index<LOGN, G::LOGE>(t, k / RREM, k % RREM);
+        c2r_pair(v[2 * k], v[2 * k + 1], w2r[k], oi[k], oj[k]);
+        if (k == 0) {   // lane 0: packed DC/Nyquist, bin N/2 copied through (selects, not a branch)
+          const bool z = i == 0;
+          oi[0] = mk(z ? v[0].x + v[0].y : oi[0].x, z ? v[0].x - v[0].y : oi[0].y);
+          oj[0] = mk(z ? v[1].x : oj[0].x, z ? v[1].y : oj[0].y);
         }
       }
+      if constexpr (TWO) pass_first_paired<LOGN, G::LOGE, FWD>(v, t, oi, oj, tab2);
+      else pass_first_paired<LOGN, G::LOGE, FWD>(v, t, oi, oj, tab1);
       __syncthreads();
-      pass_gather_padded<LOGN, G::LOGE>(v, t, xb);
+      pass_first_paired_scatter<LOGN, G::LOGE>(v, t, xb);
+      __syncthreads();
+      constexpr int L1 = pass_last_logns(LOGN, G::LOGE) - G::LOGE;
+      if constexpr (TWO) wg_passes_dif_after<LOGN, G::LOGE, L1, FWD>(v, t, tab2, xb);
+      else wg_passes_dif_after<LOGN, G::LOGE, L1, FWD>(v, t, tab1, xb);
+    } else {
+      if constexpr (MODE == MODE_C2R) {
+        // fused reference `iconv` (cl_fft.cpp:192-205) on the way in
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E / 2; k++) {
+          const int i = t + T * k;
+          if (i == 0) {
+            xb[0] = mk(v[0].x + v[0].y, v[0].x - v[0].y);
+            xb[lds_pad(N / 2)] = v[1];
+          } else {
+            cpx oi, oj;
+            c2r_pair(v[2 * k], v[2 * k + 1], w2r[k], oi, oj);
+            xb[lds_pad(i)] = oi;
+            xb[lds_pad(N - i)] = oj;
+          }
+        }
+        __syncthreads();
+        pass_gather_padded<LOGN, G::LOGE>(v, t, xb);
+      }
+      constexpr bool PL = MODE == MODE_R2C && PAIRED;
+      if constexpr (TWO) wg_passes<LOGN, G::LOGE, 0, FWD, PL>(v, t, tab2, xb);
+      else wg_passes<LOGN, G::LOGE, 0, FWD, PL>(v, t, tab1, xb);
     }
-
-    if constexpr (TWO) wg_passes<LOGN, G::LOGE, 0, FWD>(v, t, tab2, xb);
-    else wg_passes<LOGN, G::LOGE, 0, FWD>(v, t, tab1, xb);
 
     if constexpr (SCALE) {
       constexpr float inv = 1.0f / (float)N;
@@ -153,7 +187,20 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     // group whose transform index is past the batch were clamped to the LAST transform: they
     // loaded the same input in the same instruction as its owner and store bit-identical output.
     (void)active;
-    if constexpr (MODE == MODE_R2C) {
+    if constexpr (MODE == MODE_R2C && PAIRED) {
+      // fused reference `conv` (cl_fft.cpp:178-191): both bins of every pair are in this lane's registers
+      pairs_visit<LOGN, G::LOGE>(v, t, [&](int k, int i, cpx ci, cpx cj) {
+        const int j = i == 0 ? N / 2 : N - i;
+        cpx oi, oj;
+        r2c_pair(ci, cj, w2r[k], oi, oj);
+        if (k == 0 && i == 0) {   // packed DC/Nyquist; bin N/2 copied through
+          oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
+          oj = cj;
+        }
+        st_nt(x + i, oi);
+        st_nt(x + j, oj);
+      });
+    } else if constexpr (MODE == MODE_R2C) {
       // fused reference `conv` (cl_fft.cpp:178-191) on the way out
       __syncthreads();
 #pragma unroll

@@ -5,7 +5,9 @@
 
 namespace clfa {
 
-template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
+// PAIRLAST: the last pass is pass_last_paired — the caller picks the pairs up with pairs_visit
+// instead of storing positions tid + T*e.
+template <int LOGN, int LOGE, int LOGNS, bool FWD, bool PAIRLAST = false, class Tab>
 __device__ __forceinline__ void wg_passes(cpx (&v)[1 << LOGE], int t, const Tab &tab, cpx *xb) {
   pass_compute<LOGN, LOGE, LOGNS, FWD>(v, t, tab);
   constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
@@ -13,8 +15,27 @@ __device__ __forceinline__ void wg_passes(cpx (&v)[1 << LOGE], int t, const Tab 
     __syncthreads();  // everybody is done reading the previous exchange
     pass_scatter_padded<LOGN, LOGE, LOGNS>(v, t, xb);
     __syncthreads();
-    pass_gather_padded<LOGN, LOGE>(v, t, xb);
-    wg_passes<LOGN, LOGE, LOGNS + LOGR, FWD>(v, t, tab, xb);
+    constexpr int NEXT = LOGNS + LOGR;
+    if constexpr (PAIRLAST && NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN) {
+      pass_last_paired<LOGN, LOGE, FWD>(v, t, tab, xb);
+    } else {
+      pass_gather_padded<LOGN, LOGE>(v, t, xb);
+      wg_passes<LOGN, LOGE, NEXT, FWD, PAIRLAST>(v, t, tab, xb);
+    }
+  }
+}
+
+// the transposed chain from the pass (2^LOGNS, radix 2^LOGE) downwards; v holds what the pass
+// before it (a bigger LOGNS) has just computed, i.e. positions tid + T*e
+template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
+__device__ __forceinline__ void wg_passes_dif_after(cpx (&v)[1 << LOGE], int t, const Tab &tab, cpx *xb) {
+  dif_gather_padded<LOGN, LOGE, LOGNS>(v, t, xb);
+  dif_compute<LOGN, LOGE, LOGNS, FWD>(v, t, tab);
+  if constexpr (LOGNS > 0) {
+    __syncthreads();
+    dif_scatter_padded<LOGN, LOGE>(v, t, xb);
+    __syncthreads();
+    wg_passes_dif_after<LOGN, LOGE, LOGNS - LOGE, FWD>(v, t, tab, xb);
   }
 }
 
@@ -34,26 +55,5 @@ template <int LOGN> struct LdsGeom {
   static constexpr int PADN = lds_padded_size(N);
   static constexpr int HALF = N / 2 > 0 ? N / 2 : 1;
 };
-
-// reference conv kernel, cl_fft.cpp:178-191 (pair i, M-i; bin M/2 not visited)
-__device__ __forceinline__ void r2c_pair(cpx ci, cpx cjraw, cpx w, cpx &oi, cpx &oj) {
-  cpx cj = cconj(cjraw);
-  cpx e = cscale(cadd(ci, cj), .5f);
-  cpx d = csub(cj, ci);
-  cpx o = cscale(mk(-d.y, d.x), .5f);
-  cpx p = cmul(w, o);
-  oi = cadd(e, p);
-  oj = cconj(csub(e, p));
-}
-// reference iconv kernel, cl_fft.cpp:192-205
-__device__ __forceinline__ void c2r_pair(cpx ci, cpx cjraw, cpx w, cpx &oi, cpx &oj) {
-  cpx cj = cconj(cjraw);
-  cpx e = cscale(cadd(ci, cj), .5f);
-  cpx d = csub(ci, cj);
-  cpx o = cscale(mk(-d.y, d.x), .5f);
-  cpx p = cmul(w, o);
-  oi = cadd(e, p);
-  oj = cconj(csub(e, p));
-}
 
 }  // namespace clfa

@@ -116,6 +116,128 @@ template <int LOGN, int LOGE, int LOGLO, bool FWD> static int two_level() {
   printf("n=2^%-2d E=%-2d two-level table vs exact table: relL2 %.3g\n", LOGN, E, e);
   return !(e < 3e-7);
 }
+// ---- packed real transforms with the pair maps done in registers ---------------------------
+// forward: pass chain whose last (remainder) pass is pass_last_paired, pairs picked up by pairs_visit;
+// inverse: pass_first_paired + the transposed (decimation-in-frequency) chain.  Yardstick: the plain chain plus the
+// reference's pair loops (cl_fft.cpp:178-205) over natural-order arrays.
+template <int LOGN, int LOGE, int LOGNS>
+static void run_pairlast(std::vector<cpx> &regs, const std::vector<cpx> &tab, std::vector<cpx> &lds) {
+  constexpr int E = 1 << LOGE, T = 1 << (LOGN - LOGE);
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS), NEXT = LOGNS + LOGR;
+  for (int tid = 0; tid < T; tid++)
+    pass_compute<LOGN, LOGE, LOGNS, true>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, tab);
+  for (int tid = 0; tid < T; tid++)
+    pass_scatter_padded<LOGN, LOGE, LOGNS>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+  if constexpr (NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN) {
+    for (int tid = 0; tid < T; tid++)
+      pass_last_paired<LOGN, LOGE, true>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, tab, lds.data());
+  } else {
+    for (int tid = 0; tid < T; tid++)
+      pass_gather_padded<LOGN, LOGE>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+    run_pairlast<LOGN, LOGE, NEXT>(regs, tab, lds);
+  }
+}
+template <int LOGN, int LOGE, int LOGNS>
+static void run_dif_inv(std::vector<cpx> &regs, const std::vector<cpx> &tab, std::vector<cpx> &lds) {
+  constexpr int E = 1 << LOGE, T = 1 << (LOGN - LOGE);
+  for (int tid = 0; tid < T; tid++) {
+    auto &v = *reinterpret_cast<cpx(*)[E]>(&regs[tid * E]);
+    dif_gather_padded<LOGN, LOGE, LOGNS>(v, tid, lds.data());
+    dif_compute<LOGN, LOGE, LOGNS, false>(v, tid, tab);
+  }
+  if constexpr (LOGNS > 0) {
+    for (int tid = 0; tid < T; tid++)
+      dif_scatter_padded<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+    run_dif_inv<LOGN, LOGE, LOGNS - LOGE>(regs, tab, lds);
+  }
+}
+template <int LOGN, int LOGE> static int paired() {
+  constexpr int m = 1 << LOGN, E = 1 << LOGE, T = m / E, R = 1 << pass_rem_logr(LOGN, LOGE), U = E / R;
+  static_assert(pair_ok(LOGN, LOGE), "");
+  std::vector<cpx> x(m), tab(m / 2), w2f(m), w2i(m), regs(m), lds(lds_padded_size(m));
+  unsigned s = 4242u + LOGN;
+  for (auto &c : x) {
+    s = s * 1664525u + 1013904223u; c.x = (float)(s >> 8) / 8388608.0f - 1.0f;
+    s = s * 1664525u + 1013904223u; c.y = (float)(s >> 8) / 8388608.0f - 1.0f;
+  }
+  const double PI = 3.141592653589793;
+  for (int i = 0; i < m / 2; i++) tab[i] = mk((float)cos(i * 2 * PI / m), -(float)sin(i * 2 * PI / m));
+  for (int i = 0; i < m; i++) {
+    w2f[i] = mk((float)cos(i * PI / m), -(float)sin(i * PI / m));
+    w2i[i] = mk((float)cos(i * PI / m), (float)sin(i * PI / m));
+  }
+  int bad = 0;
+  // ---- forward ----
+  std::vector<cpx> z(m), want(m), got(m);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) regs[tid * E + e] = x[tid + T * e];
+  run<LOGN, LOGE, 0, true>(regs, tab, lds);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) z[tid + T * e] = regs[tid * E + e];
+  want = z;
+  want[0] = mk((z[0].x + z[0].y) * .5f, (z[0].x - z[0].y) * .5f);
+  for (int i = 1; i < m / 2; i++) r2c_pair(z[i], z[m - i], w2f[i], want[i], want[m - i]);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) regs[tid * E + e] = x[tid + T * e];
+  run_pairlast<LOGN, LOGE, 0>(regs, tab, lds);
+  std::vector<int> seen(m, 0);
+  for (int tid = 0; tid < T; tid++)
+    pairs_visit<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, [&](int k, int i, cpx ci, cpx cj) {
+      (void)k;
+      const int j = i == 0 ? m / 2 : m - i;
+      cpx oi, oj;
+      r2c_pair(ci, cj, w2f[i], oi, oj);
+      if (i == 0) {
+        oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
+        oj = cj;
+      }
+      if (i < 0 || i >= m / 2 + (i == 0)) bad |= 1;
+      got[i] = oi; got[j] = oj; seen[i]++; seen[j]++;
+    });
+  for (int i = 0; i < m; i++)
+    if (seen[i] != 1 || got[i].x != want[i].x || got[i].y != want[i].y) bad |= 2;
+  // ---- inverse ----
+  std::vector<cpx> y = x;
+  y[0] = mk(x[0].x + x[0].y, x[0].x - x[0].y);
+  for (int i = 1; i < m / 2; i++) c2r_pair(x[i], x[m - i], w2i[i], y[i], y[m - i]);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) regs[tid * E + e] = y[tid + T * e];
+  run<LOGN, LOGE, 0, false>(regs, tab, lds);
+  std::vector<cpx> wanti(m);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) wanti[tid + T * e] = regs[tid * E + e];
+  std::fill(seen.begin(), seen.end(), 0);
+  for (int tid = 0; tid < T; tid++) {
+    cpx oi[E / 2], oj[E / 2];
+    for (int u = 0; u < U / 2; u++)
+      for (int q = 0; q < R; q++) {
+        const int k = u * R + q, i = pair_index<LOGN, LOGE>(tid, u, q), j = i == 0 ? m / 2 : m - i;
+        c2r_pair(x[i], x[j], w2i[i], oi[k], oj[k]);
+        if (i == 0) {
+          oi[k] = mk(x[0].x + x[0].y, x[0].x - x[0].y);
+          oj[k] = x[j];
+        }
+        seen[i]++; seen[j]++;
+      }
+    pass_first_paired<LOGN, LOGE, false>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, oi, oj, tab);
+  }
+  for (int i = 0; i < m; i++) if (seen[i] != 1) bad |= 4;
+  for (int tid = 0; tid < T; tid++)
+    pass_first_paired_scatter<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+  run_dif_inv<LOGN, LOGE, pass_last_logns(LOGN, LOGE) - LOGE>(regs, tab, lds);
+  double num = 0, den = 0;
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) {
+      cpx a = regs[tid * E + e], b = wanti[tid + T * e];
+      num += (double)(a.x - b.x) * (a.x - b.x) + (double)(a.y - b.y) * (a.y - b.y);
+      den += (double)b.x * b.x + (double)b.y * b.y;
+    }
+  double e = sqrt(num / den);
+  if (!(e < 5e-7)) bad |= 8;
+  printf("m=2^%-2d E=%-2d paired r2c %s, paired c2r relL2 %.3g%s\n", LOGN, E, (bad & 3) ? "MISMATCH" : "bit-exact", e,
+         bad ? "  FAIL" : "");
+  return bad != 0;
+}
 template <int LOGN, int LOGE> static void both() {
   double a = check<LOGN, LOGE, true>(), b = check<LOGN, LOGE, false>();
   printf("n=2^%-2d E=%-2d relL2 fwd %.3g inv %.3g\n", LOGN, 1 << LOGE, a, b);
@@ -128,6 +250,8 @@ int main() {
   both<6, 2>(); both<6, 3>(); both<10, 3>(); both<9, 2>(); both<7, 3>(); both<8, 3>();
   both<5, 5>(); both<10, 5>(); both<13, 5>(); both<12, 5>(); both<8, 5>();   // 32 points per lane (radix-32 passes)
   g_fail |= two_level<13, 5, 6, true>() | two_level<13, 5, 6, false>() | two_level<12, 4, 6, true>();
+  g_fail |= paired<5, 4>() | paired<6, 4>() | paired<7, 4>() | paired<9, 4>() | paired<10, 4>() | paired<11, 4>() |
+            paired<13, 4>() | paired<4, 3>() | paired<5, 3>() | paired<7, 3>();
   puts(g_fail ? "FAIL" : "OK");
   return g_fail;
 }
