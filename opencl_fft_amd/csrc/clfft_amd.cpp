@@ -157,6 +157,9 @@ struct clfa_fft {
   hipStream_t stream = nullptr;
   DevBuf half, w2, four, scratch, stage, ctl;
   FftTables tabs;
+  // n > 65536 (extension): n = N1 x N2; `tabs` then belongs to the N2-point row transform
+  BigGeom big{};
+  DevBuf bigtabs, scratch2;
 };
 
 struct clfa_pconv {
@@ -282,8 +285,8 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
   p->n = n;
   p->size = size;
   p->log[0] = 0;
-  if (!is_pow2(n) || n < 2 || n > (1 << kMaxLog)) {
-    snprintf(p->log, sizeof(p->log), "size must be a power of two, complex length 2..65536 (got %d)", n);
+  if (!is_pow2(n) || n < 2 || n > (1 << kBigMaxLog)) {
+    snprintf(p->log, sizeof(p->log), "size must be a power of two, complex length 2..%d (got %d)", 1 << kBigMaxLog, n);
     return CLFA_INVALID_VALUE;
   }
   p->logn = ilog2(n);
@@ -292,28 +295,47 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   std::vector<cpx> h;
-  if (p->logn <= kLdsMaxLog) {
-    if (kLdsTwoLevel(p->logn)) {
+  int rown = n, rowlog = p->logn;   // the transform the LDS / four-step tables are for
+  if (p->logn > kMaxLog) {
+    big_split(p->logn, &p->big);
+    rowlog = p->big.logn2;
+    rown = 1 << rowlog;
+    const int n1 = 1 << p->big.logn1, lo = 1 << p->big.loglo;
+    std::vector<cpx> all, part;
+    fill_twiddle(part, n1 / 2, n1, 1, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + n1 / 2);
+    fill_twiddle(part, lo, n, 1, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + lo);
+    fill_twiddle(part, n / lo, n, lo, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + n / lo);
+    if ((e = upload(p->bigtabs, all.data(), sizeof(cpx) * all.size()))) return e;
+    // workspace: as many whole transforms as fit 256 MiB (at least one); exec walks the batch in such chunks
+    size_t per = sizeof(cpx) * (size_t)n, cap = (size_t)256 << 20;
+    if ((e = p->scratch.ensure(per * (cap / per > 0 ? cap / per : 1)))) return e;
+  }
+  if (rowlog <= kLdsMaxLog) {
+    if (kLdsTwoLevel(rowlog)) {
       // two-level table: hi[j] = W_n^(64 j), j < n/64, then lo[j] = W_n^j, j < 64
       const int lo = 1 << kLdsTwoLevelLogLo;
       std::vector<cpx> part;
-      fill_twiddle(h, n / lo, n, lo, -1.f);
-      fill_twiddle(part, lo, n, 1, -1.f);
-      h.resize(n / lo);
+      fill_twiddle(h, rown / lo, rown, lo, -1.f);
+      fill_twiddle(part, lo, rown, 1, -1.f);
+      h.resize(rown / lo);
       h.insert(h.end(), part.begin(), part.begin() + lo);
     } else {
-      fill_twiddle(h, n / 2, n, 1, -1.f);
+      fill_twiddle(h, rown / 2, rown, 1, -1.f);
     }
     if ((e = upload(p->half, h.data(), sizeof(cpx) * h.size()))) return e;
     p->tabs.half = (const cpx *)p->half.p;
   } else {
     std::vector<cpx> all;
-    fill_fourstep_tables(all, p->logn);
+    fill_fourstep_tables(all, rowlog);
     if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
     p->tabs.four = (const cpx *)p->four.p;
-    size_t sbytes = (size_t)fourstep_grid(p->logn, p->variant, p->di) * n * sizeof(cpx);
-    if (p->variant == kVariantCoop) sbytes = coop_scratch_bytes(p->logn);
-    if ((e = p->scratch.ensure(sbytes))) return e;
+    size_t sbytes = (size_t)fourstep_grid(rowlog, p->variant, p->di) * rown * sizeof(cpx);
+    if (p->variant == kVariantCoop) sbytes = coop_scratch_bytes(rowlog);
+    DevBuf &ws = p->logn > kMaxLog ? p->scratch2 : p->scratch;
+    if ((e = ws.ensure(sbytes))) return e;
     if ((e = p->ctl.ensure(coop_ctl_bytes() > coop2_ctl_bytes() ? coop_ctl_bytes() : coop2_ctl_bytes()))) return e;
   }
   if (real) {
@@ -339,7 +361,7 @@ int clfa_rfft_create(clfa_fft **plan, int device, int size, int forward) {
   if (!p) return CLFA_OUT_OF_HOST_MEMORY;
   if (size < 4 || !is_pow2(size)) {
     p->log[0] = 0;
-    snprintf(p->log, sizeof(p->log), "real size must be a power of two, 4..131072 (got %d)", size);
+    snprintf(p->log, sizeof(p->log), "real size must be a power of two, 4..%d (got %d)", 2 << kBigMaxLog, size);
     p->err = CLFA_INVALID_VALUE;
   } else {
     p->err = fft_setup(p, device, size / 2, true, size, forward != 0);
@@ -361,21 +383,25 @@ void clfa_fft_destroy(clfa_fft *p) {
   p->scratch.release();
   p->stage.release();
   p->ctl.release();
+  p->bigtabs.release();
+  p->scratch2.release();
   delete p;
 }
 
 int clfa_fft_get_error(const clfa_fft *p) { return p ? p->err : CLFA_INVALID_VALUE; }
 const char *clfa_fft_get_log(const clfa_fft *p) { return p ? p->log : ""; }
-size_t clfa_fft_workspace_bytes(const clfa_fft *p) { return p ? p->scratch.bytes : 0; }
+size_t clfa_fft_workspace_bytes(const clfa_fft *p) { return p ? p->scratch.bytes + p->scratch2.bytes : 0; }
 
 const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
+  if (p->logn > kMaxLog) return "k_big_cols";
   return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn, p->fwd, p->variant);
 }
 
 int clfa_fft_set_variant(clfa_fft *p, int variant) {
   if (!p || variant < 0 || variant > kVariantMax) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
+  if (p->logn > kMaxLog) return variant == 0 ? CLFA_SUCCESS : CLFA_INVALID_VALUE;
   p->variant = variant;
   if (p->logn > kLdsMaxLog) {
     HIP_TRY(hipSetDevice(p->di.device));
@@ -394,6 +420,10 @@ int clfa_fft_sync_check(clfa_fft *p, void *stream) {
   HIP_TRY(hipSetDevice(p->di.device));
   hipStream_t s = (hipStream_t)stream;
   unsigned err = 0;
+  if (p->logn > kMaxLog) {
+    HIP_TRY(hipStreamSynchronize(s));
+    return CLFA_SUCCESS;
+  }
   if (p->logn > kLdsMaxLog && p->variant == kVariantCoop && p->ctl.p) HIP_TRY(coop_read_error(p->ctl.p, &err, s));
   if (p->logn > kLdsMaxLog && p->variant == kVariantCoop2 && p->ctl.p) HIP_TRY(coop2_read_error(p->ctl.p, &err, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -415,7 +445,14 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
     return CLFA_SUCCESS;
   }
   if (p->real && !p->fwd) HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, p->n, batch, s));
-  if (p->variant == kVariantCoop)
+  if (p->logn > kMaxLog) {
+    const long cb = (long)(p->scratch.bytes / (sizeof(cpx) * (size_t)p->n));
+    for (long b0 = 0; b0 < batch; b0 += cb) {
+      const long nb = batch - b0 < cb ? batch - b0 : cb;
+      HIP_TRY(launch_fft_big(p->big, p->fwd, scale, d + b0 * (long)p->n, (cpx *)p->scratch.p, (cpx *)p->scratch2.p,
+                             (const cpx *)p->bigtabs.p, p->tabs, nb, p->di, s));
+    }
+  } else if (p->variant == kVariantCoop)
     HIP_TRY(launch_fft_coop(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));
   else if (p->variant == kVariantCoop2)
     HIP_TRY(launch_fft_coop2(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));

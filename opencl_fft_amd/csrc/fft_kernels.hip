@@ -637,7 +637,7 @@ const char *name_fft_4step(int, bool, int) { return "k_fft_4step"; }
 
 
 // ---------------------------------------------------------------------------------
-// XCD-cooperative four-step FFT (the default for n = 2^14 .. 2^16)
+// XCD-cooperative four-step FFT (variants 7 and 8; measured slower than the simple kernel, kept selectable)
 // ---------------------------------------------------------------------------------
 // Measured on MI355X (profiles/membench_r01.txt): a per-workgroup 512 KiB scratch costs a
 // full extra pass (3.6 TB/s algorithmic at best), but scratch that stays hot in the XCD's
@@ -1114,6 +1114,118 @@ hipError_t launch_fft_coop(int logn, bool fwd, bool scale, cpx *data, cpx *scrat
 // reads the error word of the last cooperative launch (0 = no spin ever timed out)
 hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s) {
   return hipMemcpyAsync(err, &((const CoopCtl *)ctl)->error.v, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+}
+
+// ---------------------------------------------------------------------------------
+// n = 2^17 .. 2^24: beyond the reference's reach (its stage kernel overflows int32 above 65536,
+// cl_fft.cpp:32) — an extension, composed from the kernels above
+// ---------------------------------------------------------------------------------
+// n = N1 x N2, N1 = 32..256 (columns), N2 = 4096..65536 (rows):
+//   1. k_big_cols: N1-point FFT down 16..128 adjacent columns of data[n1][n2], times W_n^(n2 k1),
+//      to scratch[k1][n2]                                                       (16 B/sample)
+//   2. the batched row kernel of this file over the n-contiguous rows of scratch, N1 * batch of them,
+//      in place: k_fft_lds (N2 <= 8192, 16 B/sample) or the four-step kernel (32 B/sample)
+//   3. k_big_transpose: scratch[k1][k2] -> data[k2 * N1 + k1] (natural order), times 1/n for forward
+//      plans                                                                     (16 B/sample)
+// Twiddles W_n^e = lo[e mod 4096] * hi[e / 4096], both tables rounded from double, read from global
+// memory (64 KiB in all: cache-resident).
+
+int big_split(int logn, BigGeom *g) {
+  if (logn <= kMaxLog || logn > kBigMaxLog) return -1;
+  g->logn = logn;
+  g->logn2 = logn <= 20 ? 12 : (logn == 21 ? 13 : logn - 8);
+  g->logn1 = logn - g->logn2;
+  g->loglo = 12;
+  return 0;
+}
+
+template <int LOGN1, bool FWD>
+__global__ __launch_bounds__(256) void k_big_cols(const cpx *__restrict__ data, cpx *__restrict__ scratch,
+                                                  const cpx *__restrict__ tabs_g, int logn2, int loglo) {
+  constexpr int N1 = 1 << LOGN1, T1 = N1 / 16, C1 = 256 / T1;
+  __shared__ cpx s_tab1[N1 / 2];
+  __shared__ cpx s_x[N1 * C1];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N1 / 2; i += 256) s_tab1[i] = tabs_g[i];
+  const cpx *tlo = tabs_g + N1 / 2, *thi = tlo + (1 << loglo);
+  const int col = tid % C1, tf = tid / C1;
+  const int n2 = blockIdx.x * C1 + col;
+  const long base = ((long)blockIdx.y << (LOGN1 + logn2)) + n2;
+  cpx v[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = ld_nt(data + base + ((long)(tf + T1 * e) << logn2));
+  __syncthreads();
+  pass_compute<LOGN1, 4, 0, FWD>(v, tf, s_tab1);
+  pass_scatter<LOGN1, 4, 0>(v, tf, [&](int p, cpx val) { s_x[p * C1 + col] = val; });
+  __syncthreads();
+  pass_gather<LOGN1, 4>(v, tf, [&](int p) { return s_x[p * C1 + col]; });
+  pass_compute<LOGN1, 4, 4, FWD>(v, tf, s_tab1);
+  const int mlo = (1 << loglo) - 1;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int k1 = tf + T1 * e;
+    const int ex = n2 * k1;  // < n <= 2^24
+    cpx w = cmul(tlo[ex & mlo], thi[ex >> loglo]);
+    if (!FWD) w.y = -w.y;
+    scratch[base + ((long)k1 << logn2)] = cmul(v[e], w);
+  }
+}
+
+template <int LOGN1, bool SCALE>
+__global__ __launch_bounds__(256) void k_big_transpose(const cpx *__restrict__ scratch, cpx *__restrict__ data,
+                                                       int logn2, float inv_n) {
+  constexpr int N1 = 1 << LOGN1, TK1 = N1 < 64 ? N1 : 64, TK2 = 4096 / TK1;
+  __shared__ cpx tile[TK1 * (TK2 + 1)];
+  const int tid = threadIdx.x;
+  const int k2_0 = blockIdx.x * TK2, k1_0 = blockIdx.y * TK1;
+  const long tbase = (long)blockIdx.z << (LOGN1 + logn2);
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int i = tid + 256 * r, k1 = i / TK2, k2 = i % TK2;
+    tile[k1 * (TK2 + 1) + k2] = scratch[tbase + ((long)(k1_0 + k1) << logn2) + k2_0 + k2];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int i = tid + 256 * r, k2 = i / TK1, k1 = i % TK1;
+    cpx o = tile[k1 * (TK2 + 1) + k2];
+    if constexpr (SCALE) o = cscale(o, inv_n);
+    st_nt(data + tbase + ((long)(k2_0 + k2) << LOGN1) + k1_0 + k1, o);
+  }
+}
+
+template <int LOGN1>
+static hipError_t launch_big_n1(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, cpx *scratch2,
+                                const cpx *bigtabs, const FftTables &sub, long batch, const DeviceInfo &di,
+                                hipStream_t s) {
+  constexpr int N1 = 1 << LOGN1, T1 = N1 / 16, C1 = 256 / T1, TK1 = N1 < 64 ? N1 : 64, TK2 = 4096 / TK1;
+  const int n2 = 1 << g.logn2;
+  const dim3 gc(n2 / C1, (unsigned)batch), gt(n2 / TK2, N1 / TK1, (unsigned)batch);
+  if (fwd) hipLaunchKernelGGL((k_big_cols<LOGN1, true>), gc, dim3(256), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  else hipLaunchKernelGGL((k_big_cols<LOGN1, false>), gc, dim3(256), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (g.logn2 <= kLdsMaxLog) e = launch_fft_lds(g.logn2, fwd, MODE_C2C, false, scratch, sub, batch * N1, di, s);
+  else e = launch_fft_4step(g.logn2, fwd, false, 0, scratch, scratch2, sub, batch * N1, di, s);
+  if (e != hipSuccess) return e;
+  const float inv_n = 1.0f / (float)(1L << g.logn);
+  if (scale) hipLaunchKernelGGL((k_big_transpose<LOGN1, true>), gt, dim3(256), 0, s, scratch, data, g.logn2, inv_n);
+  else hipLaunchKernelGGL((k_big_transpose<LOGN1, false>), gt, dim3(256), 0, s, scratch, data, g.logn2, inv_n);
+  return hipGetLastError();
+}
+
+// scratch: `batch` transforms (the caller chunks); scratch2: the four-step workspace when N2 > 8192
+hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, cpx *scratch2,
+                          const cpx *bigtabs, const FftTables &sub, long batch, const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  if (batch > 65535) return hipErrorInvalidValue;
+  switch (g.logn1) {
+    case 5: return launch_big_n1<5>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
+    case 6: return launch_big_n1<6>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
+    case 7: return launch_big_n1<7>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
+    case 8: return launch_big_n1<8>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 // ---------------------------------------------------------------------------------

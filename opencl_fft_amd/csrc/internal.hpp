@@ -55,6 +55,17 @@ hipError_t launch_fft_coop2(int logn, bool fwd, bool scale, cpx *data, cpx *scra
                             long batch, const DeviceInfo &di, hipStream_t s);
 hipError_t coop2_read_error(const void *ctl, unsigned *err, hipStream_t s);
 
+// n = 2^17 .. 2^kBigMaxLog (extension: the reference overflows above 65536): columns + rows + transpose
+constexpr int kBigMaxLog = 24;
+struct BigGeom {
+  int logn, logn1, logn2, loglo;   // n = 2^logn1 x 2^logn2; twiddle tables lo (2^loglo) / hi (n >> loglo)
+};
+int big_split(int logn, BigGeom *g);
+// bigtabs: [half N1 | lo | hi]; sub: tables of the 2^logn2 row transform; scratch holds `batch`
+// transforms (batch <= 65535), scratch2 the row transform's own workspace (logn2 > kLdsMaxLog)
+hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, cpx *scratch2,
+                          const cpx *bigtabs, const FftTables &sub, long batch, const DeviceInfo &di, hipStream_t s);
+
 // stand-alone pack / unpack (reference kernels conv / iconv) for M above the LDS path
 hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
 hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);

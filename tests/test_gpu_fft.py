@@ -96,7 +96,7 @@ def test_cfft_empty_batch_and_bad_sizes():
     plan = fa.Clcfft(0, 64, True)
     assert plan.transform(np.zeros((0, 64), np.complex64)) == 0
     assert plan.transform(np.zeros(32, np.complex64)) == -30
-    for n in (0, 1, 3, 1000, 131072):
+    for n in (0, 1, 3, 1000, 1 << 25):
         bad = fa.Clcfft(0, n, True)
         assert bad.get_error() == -30 and fa.cl_error_string(bad.get_error()) == "Invalid value"
         assert bad.transform(np.zeros(max(n, 1), np.complex64)) == -30
@@ -199,7 +199,7 @@ def test_rfft_batched_in_place(size, batch):
 
 
 def test_rfft_bad_sizes():
-    for s in (0, 2, 3, 12, 262144):
+    for s in (0, 2, 3, 12, 1 << 26):
         assert fa.Clrfft(0, s, True).get_error() == -30
 
 
@@ -261,3 +261,67 @@ def test_cfft_cooperative_kernel(n, batch, variant):
         assert plan.sync_check() == 0, "a dependency wait timed out inside the cooperative kernel"
         want = oracle.cfft(x if batch <= 40 else x[::13], fwd)
         assert_parity(y if batch <= 40 else y[::13], want, what="coop n=%d batch=%d fwd=%s" % (n, batch, fwd))
+
+
+# ---- beyond the reference: n = 2^17 .. 2^24 ---------------------------
+# The reference's stage kernel overflows int32 above 65536 (cl_fft.cpp:32), so there is nothing of its
+# own to compare with: the yardstick is numpy's float64 FFT under the reference's conventions
+# (forward scaled by 1/n, inverse unscaled), same norm-relative 1e-6 criterion.
+
+@pytest.mark.parametrize("logn,batch", [(17, 3), (18, 2), (19, 1), (20, 2), (21, 1), (22, 1), (24, 1)])
+def test_cfft_big_sizes(logn, batch):
+    n = 1 << logn
+    rng = np.random.default_rng(logn)
+    x = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    assert f.get_error() == 0 and i.get_error() == 0
+    assert f.workspace_bytes() >= 8 * n
+    y = x.copy()
+    assert f.transform(y) == 0
+    want = (np.fft.fft(x.astype(np.complex128), axis=-1) / n)
+    assert_parity(y, want.astype(np.complex64), what="fwd 2^%d" % logn)
+    z = x.copy()
+    assert i.transform(z) == 0
+    want = np.fft.ifft(x.astype(np.complex128), axis=-1) * n
+    assert_parity(z, want.astype(np.complex64), what="inv 2^%d" % logn)
+    assert i.transform(y) == 0                       # round trip
+    assert_parity(y, x, what="round trip 2^%d" % logn)
+
+
+def test_cfft_big_batch_chunks():
+    """more transforms than the 256 MiB workspace holds at once: exec walks the batch in chunks"""
+    import torch
+    n, batch = 1 << 17, 300                              # 1 MiB each, workspace = 256 of them
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
+    x = d.clone()
+    assert f.exec_device(d, batch) == 0
+    y = d[[0, 255, 256, 299]].cpu().numpy().view(np.complex64).reshape(4, n)
+    x4 = x[[0, 255, 256, 299]].cpu().numpy().view(np.complex64).reshape(4, n)
+    assert_parity(y, (np.fft.fft(x4.astype(np.complex128), axis=-1) / n).astype(np.complex64), what="chunked fwd")
+    assert i.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    err = float((d - x).norm() / x.norm())
+    assert err < 1e-6, err
+
+
+def test_rfft_big_size():
+    """packed real transform above 131072 points: same packing rules as the reference's (bin M/2 left
+    un-conjugated, amplitude scaling), checked against the oracle's pack applied to a float64 FFT"""
+    size = 1 << 19
+    m = size // 2
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, size).astype(np.float32)
+    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+    assert f.get_error() == 0 and i.get_error() == 0
+    c = np.zeros(m, np.complex64)
+    assert f.transform(c, x) == 0
+    X = np.fft.fft(x.astype(np.float64))
+    want = np.empty(m, np.complex128)
+    want[0] = X[0].real / size + 1j * X[m].real / size
+    want[1:] = 2 * X[1:m] / size
+    want[m // 2] = np.conj(want[m // 2])                 # SURVEY.md section 8a fact 2
+    assert_parity(c, want.astype(np.complex64), what="big r2c")
+    r = np.zeros(size, np.float32)
+    assert i.transform(c, r) == 0
+    assert_parity(r, x, what="big rfft round trip")
