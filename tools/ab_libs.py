@@ -1,0 +1,53 @@
+"""dev tool: interleaved A/B of two builds of libclfft_amd.so in ONE process, on realistic data
+(steps alternate forward / inverse plans so the values stay O(1): all-zero or inf data draw less
+power and run at higher clocks, which flatters repeated same-direction loops).
+usage: python tools/ab_libs.py <old.so> [rfft|c2c|c2c8192]"""
+import ctypes as C, statistics, sys
+sys.path.insert(0, ".")
+import torch
+import opencl_fft_amd._lib as L
+
+new = L.lib()
+old = C.CDLL(sys.argv[1])
+for name, res, args in L.SYMBOLS:
+    f = getattr(old, name); f.restype = res; f.argtypes = args
+what = sys.argv[2] if len(sys.argv) > 2 else "rfft"
+
+def plans(lib):
+    out = []
+    for fwd in (1, 0):
+        h = C.c_void_p()
+        if what == "rfft":
+            e = lib.clfa_rfft_create(C.byref(h), 0, 16384, fwd)
+        else:
+            e = lib.clfa_cfft_create(C.byref(h), 0, 8192 if what == "c2c8192" else 65536, fwd)
+        assert e == 0
+        out.append(h)
+    return out
+
+if what == "rfft":
+    batch, d = 8192, torch.rand((8192, 16384), device="cuda") * 2 - 1
+    unit = 8192 * 16384 * 8
+elif what == "c2c8192":
+    batch, d = 32768, torch.rand((32768, 8192, 2), device="cuda") * 2 - 1
+    unit = 32768 * 8192 * 16
+else:
+    batch, d = 4096, torch.rand((4096, 65536, 2), device="cuda") * 2 - 1
+    unit = 4096 * 65536 * 16
+libs = {"new": (new, plans(new)), "old": (old, plans(old))}
+s = torch.cuda.current_stream().cuda_stream
+def run(lib, ps, k):
+    for j in range(k):
+        assert lib.clfa_fft_exec_dev(ps[j % 2], d.data_ptr(), batch, s) == 0
+for lib, ps in libs.values():
+    run(lib, ps, 4)
+torch.cuda.synchronize()
+times = {k: [] for k in libs}
+for r in range(9):
+    for k, (lib, ps) in libs.items():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(lib, ps, 10); b.record(); torch.cuda.synchronize()
+        times[k].append(a.elapsed_time(b) / 10)
+for k, t in times.items():
+    m = statistics.median(t)
+    print("%s: median %.4f ms  min %.4f ms  alg %.2f TB/s" % (k, m, min(t), unit / m / 1e9))

@@ -1,4 +1,6 @@
-"""dev tool: time the large-N kernel variants with HIP events (run on the GPU box)."""
+"""dev tool: time the kernels with HIP events (run on the GPU box).  Every loop alternates forward and
+inverse plans so the data stay O(1): repeating one direction drives the values to zero (forward is
+scaled by 1/n) or to inf, and such data run measurably faster than real ones (lower power)."""
 import sys
 import numpy as np
 import torch
@@ -14,6 +16,13 @@ def timeit(fn, iters=10, warm=3):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
 
+def alt(f, i, d, batch):
+    k = [0]
+    def step():
+        (f if k[0] % 2 == 0 else i).exec_device(d, batch)
+        k[0] += 1
+    return step
+
 def main():
     n, batch = 65536, 4096
     d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
@@ -21,23 +30,21 @@ def main():
     ms = timeit(lambda: d.copy_(src))
     print("copy 2GiB->2GiB: %.3f ms = %.2f TB/s (r+w)" % (ms, 2 * d.numel() * 4 / ms / 1e9))
     for variant in [int(a) for a in sys.argv[1:]] or [0]:
-        plan = fa.Clcfft(0, n, True)
-        assert plan.set_variant(variant) == 0
+        plan, inv = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+        assert plan.set_variant(variant) == 0 and inv.set_variant(variant) == 0
         d.copy_(src)
-        ms = timeit(lambda: plan.exec_device(d, batch))
+        ms = timeit(alt(plan, inv, d, batch), iters=20)
         gs = batch * n / ms / 1e6
         print("variant %d: %.3f ms  %.1f Gsamples/s  alg %.2f TB/s" % (variant, ms, gs, gs * 16 / 1e3), flush=True)
     for size, batch in [(16384, 8192)]:
         x = torch.rand((batch, size), device="cuda") * 2 - 1
         f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
-        ms = timeit(lambda: f.exec_device(x, batch))
-        print("r2c %d x %d: %.3f ms alg %.2f TB/s" % (size, batch, ms, batch * size * 8 / ms / 1e9))
-        ms = timeit(lambda: i.exec_device(x, batch))
-        print("c2r %d x %d: %.3f ms alg %.2f TB/s" % (size, batch, ms, batch * size * 8 / ms / 1e9))
+        ms = timeit(alt(f, i, x, batch), iters=20)
+        print("r2c/c2r %d x %d: %.3f ms alg %.2f TB/s" % (size, batch, ms, batch * size * 8 / ms / 1e9))
     for n, batch in [(1024, 262144), (4096, 65536), (8192, 32768), (256, 1 << 20)]:
         x = torch.rand((batch, n, 2), device="cuda") * 2 - 1
-        f = fa.Clcfft(0, n, True)
-        ms = timeit(lambda: f.exec_device(x, batch))
+        f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+        ms = timeit(alt(f, i, x, batch), iters=20)
         print("c2c %d x %d: %.3f ms alg %.2f TB/s" % (n, batch, ms, batch * n * 16 / ms / 1e9))
 
 main()
