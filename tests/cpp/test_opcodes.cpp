@@ -1,0 +1,182 @@
+// Drives csound/opcode.cpp (the four opcodes clconv, cltvconv, clfft, clrfft) through a test double of
+// Csound's plugin framework (mock_csound/plugin.h) and checks the opcode logic — buffering, latency of
+// one partition, parts == 1 -> direct convolution, 0dbfs scaling, freeze flags, zero padding to a power
+// of two — against the convolution / FFT classes driven directly (reference behaviour: opcode.cpp:157-345
+// as documented in its README; deviations from the reference's defects are listed in csound/opcode.cpp).
+#include <cl_conv.h>
+#include <cl_dconv.h>
+#include <cl_fft.h>
+#include <plugin.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using csnd::Csound;
+static unsigned g_s = 99;
+static float rnd() { g_s = g_s * 1664525u + 1013904223u; return (g_s >> 8) / 16777216.f - 0.5f; }
+static int g_bad = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAILED line %d: %s\n", __LINE__, #c); g_bad++; } } while (0)
+
+struct Inst {
+  Csound::Entry *e;
+  csnd::OpcodeBase *p;
+  INSDS ins;
+  Inst(Csound &cs, const char *name, uint32_t ksmps, std::vector<MYFLT *> outs, std::vector<MYFLT *> in) {
+    e = &cs.opcodes.at(name);
+    p = e->make();
+    ins.ksmps = ksmps;
+    p->insdshead = &ins;
+    p->offset = 0;
+    p->nsmps = ksmps;
+    e->bind(p, &cs, outs.data(), in.data());
+  }
+  ~Inst() { e->deinit(p); e->destroy(p); }
+};
+
+int main() {
+  cl_device_id ids[32];
+  cl_uint num = 0;
+  if (clGetDeviceIDs(NULL, CL_DEVICE_TYPE_ALL, 32, ids, &num) != CL_SUCCESS || num == 0) return 2;
+  Csound cs;
+  csnd::on_load(&cs);
+  // ---- the opcode table of the reference (opcode.cpp:347-352) ----
+  CHECK(cs.opcodes.size() == 4);
+  CHECK(cs.opcodes["clconv"].outtypes == "a" && cs.opcodes["clconv"].intypes == "aiiioo" && cs.opcodes["clconv"].thread == csnd::thread::ia);
+  CHECK(cs.opcodes["cltvconv"].outtypes == "a" && cs.opcodes["cltvconv"].intypes == "aakkiii" && cs.opcodes["cltvconv"].thread == csnd::thread::ia);
+  CHECK(cs.opcodes["clfft"].outtypes == "k[]" && cs.opcodes["clfft"].intypes == "k[]ii" && cs.opcodes["clfft"].thread == csnd::thread::ik);
+  CHECK(cs.opcodes["clrfft"].outtypes == "k[]" && cs.opcodes["clrfft"].intypes == "k[]ii" && cs.opcodes["clrfft"].thread == csnd::thread::ik);
+
+  const uint32_t ksmps = 64;
+  // ---- clconv, partitioned: output = Clpconv blocks one partition late ----
+  {
+    const int parts = 256, irlen = 700, blocks = 10;
+    cs.dbfs = 1.0;
+    std::vector<MYFLT> &tab = cs.tables[1];
+    tab.resize(irlen);
+    for (auto &v : tab) v = rnd() * 0.1;
+    std::vector<MYFLT> ain(ksmps), aout(ksmps);
+    MYFLT tabno = 1, pr = parts, dev = 0, skip = 0, size = 0;
+    Inst op(cs, "clconv", ksmps, {aout.data()}, {ain.data(), &tabno, &pr, &dev, &skip, &size});
+    CHECK(op.e->init(op.p) == OK);
+    std::vector<float> coefs(irlen);
+    for (int k = 0; k < irlen; k++) coefs[k] = (float)tab[k];
+    cl_conv::Clpconv ref(ids[0], irlen, parts);
+    CHECK(ref.get_cl_err() == CL_SUCCESS && ref.push_ir(coefs.data()) == CL_SUCCESS);
+    std::vector<float> x(parts * blocks), want(parts * blocks), got;
+    for (auto &v : x) v = rnd();
+    for (int b = 0; b < blocks; b++) CHECK(ref.convolution(&want[b * parts], &x[b * parts]) == CL_SUCCESS);
+    for (size_t n0 = 0; n0 < x.size(); n0 += ksmps) {
+      for (uint32_t n = 0; n < ksmps; n++) ain[n] = x[n0 + n];
+      CHECK(op.e->aperf(op.p) == OK);
+      for (uint32_t n = 0; n < ksmps; n++) got.push_back((float)aout[n]);
+    }
+    int diff = 0;
+    for (int n = 0; n < parts; n++) diff += got[n] != 0.f;                                  // latency: one partition
+    for (size_t n = parts; n < got.size(); n++) diff += got[n] != want[n - parts];
+    CHECK(diff == 0);
+    printf("clconv  partitioned (parts %d, ir %d, ksmps %u): %s\n", parts, irlen, ksmps, diff ? "MISMATCH" : "ok");
+  }
+  // ---- clconv with parts == 1: direct convolution, vsize = ksmps, no added latency; table x 0dbfs ----
+  {
+    const int irlen = 48, periods = 12;
+    cs.dbfs = 2.0;
+    std::vector<MYFLT> &tab = cs.tables[2];
+    tab.resize(irlen + 5);
+    for (auto &v : tab) v = rnd();
+    std::vector<MYFLT> ain(ksmps), aout(ksmps);
+    MYFLT tabno = 2, pr = 1, dev = 0, skip = 5, size = 0;
+    Inst op(cs, "clconv", ksmps, {aout.data()}, {ain.data(), &tabno, &pr, &dev, &skip, &size});
+    CHECK(op.e->init(op.p) == OK);
+    std::vector<float> coefs(irlen);
+    for (int k = 0; k < irlen; k++) coefs[k] = (float)(tab[5 + k] * 2.0);
+    cl_conv::Cldconv ref(ids[0], irlen, ksmps);
+    CHECK(ref.get_cl_err() == CL_SUCCESS && ref.push_ir(coefs.data()) == CL_SUCCESS);
+    int diff = 0;
+    std::vector<float> xin(ksmps), want(ksmps);
+    for (int t = 0; t < periods; t++) {
+      for (uint32_t n = 0; n < ksmps; n++) ain[n] = xin[n] = rnd();
+      CHECK(op.e->aperf(op.p) == OK);
+      CHECK(ref.convolution(want.data(), xin.data()) == CL_SUCCESS);
+      for (uint32_t n = 0; n < ksmps; n++) diff += (float)aout[n] != want[n];
+    }
+    CHECK(diff == 0);
+    printf("clconv  direct (ir %d, skip 5, 0dbfs 2): %s\n", irlen, diff ? "MISMATCH" : "ok");
+  }
+  // ---- cltvconv: two inputs scaled by 1/0dbfs, output by 0dbfs, own freeze flag per input ----
+  {
+    const int parts = 128, size = 512, blocks = 9;
+    cs.dbfs = 32768.0;
+    std::vector<MYFLT> a1(ksmps), a2(ksmps), aout(ksmps);
+    MYFLT f1 = 1, f2 = 1, pr = parts, sz = size, dev = 0;
+    Inst op(cs, "cltvconv", ksmps, {aout.data()}, {a1.data(), a2.data(), &f1, &f2, &pr, &sz, &dev});
+    CHECK(op.e->init(op.p) == OK);
+    cl_conv::Clpconv ref(ids[0], size, parts);
+    CHECK(ref.get_cl_err() == CL_SUCCESS);
+    std::vector<float> b1(parts, 0.f), b2(parts, 0.f), o(parts, 0.f), got, want(parts, 0.f);
+    int diff = 0;
+    for (int b = 0; b < blocks; b++) {
+      const bool run2 = !(b >= 4 && b < 7);          // input 2 frozen for three blocks
+      f2 = run2 ? 1 : 0;
+      for (int n0 = 0; n0 < parts; n0 += ksmps) {
+        for (uint32_t n = 0; n < ksmps; n++) {
+          a1[n] = rnd() * 32768.0;
+          a2[n] = rnd() * 32768.0;
+          b1[n0 + n] = (float)(a1[n] / 32768.0);
+          if (run2) b2[n0 + n] = (float)(a2[n] / 32768.0);
+        }
+        CHECK(op.e->aperf(op.p) == OK);
+        for (uint32_t n = 0; n < ksmps; n++) got.push_back((float)aout[n]);
+      }
+      for (int n = 0; n < parts; n++) want.push_back((float)0);   // placeholder, filled below
+      CHECK(ref.convolution(o.data(), b1.data(), b2.data()) == CL_SUCCESS);
+      for (int n = 0; n < parts; n++) want[(b + 1) * parts + n] = (float)((MYFLT)(o[n] * 32768.0));
+    }
+    for (size_t n = 0; n < got.size(); n++) diff += got[n] != want[n];
+    CHECK(diff == 0);
+    printf("cltvconv (parts %d, size %d, freeze on input 2): %s\n", parts, size, diff ? "MISMATCH" : "ok");
+  }
+  // ---- clfft / clrfft on k-rate arrays; lengths that are not powers of two are zero padded ----
+  for (int real = 0; real < 2; real++) {
+    for (int len : {32, 24}) {
+      csnd::Vector<MYFLT> in, out;
+      in.init(&cs, len);
+      for (int k = 0; k < len; k++) in[k] = rnd();
+      MYFLT fwd = 1, dev = 0;
+      Inst op(cs, real ? "clrfft" : "clfft", ksmps, {reinterpret_cast<MYFLT *>(&out)},
+              {reinterpret_cast<MYFLT *>(&in), &fwd, &dev});
+      CHECK(op.e->init(op.p) == OK);
+      CHECK(out.len() == (uint32_t)len);
+      CHECK(op.e->kperf(op.p) == OK);
+      int np2 = 2;
+      while (np2 < (real ? len : len / 2)) np2 <<= 1;
+      std::vector<float> w(real ? np2 : 2 * np2, 0.f);
+      for (int k = 0; k < len; k++) w[k] = (float)in[k];
+      int err;
+      if (real) {
+        cl_fft::Clrfft ref(ids[0], np2, true);
+        err = ref.transform(reinterpret_cast<std::complex<float> *>(w.data()));
+      } else {
+        cl_fft::Clcfft ref(ids[0], np2, true);
+        err = ref.transform(reinterpret_cast<std::complex<float> *>(w.data()));
+      }
+      CHECK(err == CL_SUCCESS);
+      int diff = 0;
+      for (int k = 0; k < len && k < (int)w.size(); k++) diff += (float)out[k] != w[k];
+      CHECK(diff == 0);
+      printf("%s k-array of %d values -> %d-point transform: %s\n", real ? "clrfft" : "clfft ", len, np2, diff ? "MISMATCH" : "ok");
+    }
+  }
+  // ---- a bad device index is an init error, not a crash ----
+  {
+    csnd::Vector<MYFLT> in, out;
+    in.init(&cs, 16);
+    MYFLT fwd = 1, dev = 31;
+    Inst op(cs, "clfft", ksmps, {reinterpret_cast<MYFLT *>(&out)}, {reinterpret_cast<MYFLT *>(&in), &fwd, &dev});
+    CHECK(op.e->init(op.p) == NOTOK);
+  }
+  puts(g_bad ? "FAIL" : "OK");
+  return g_bad ? 1 : 0;
+}

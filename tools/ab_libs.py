@@ -35,6 +35,8 @@ else:
     batch, d = 4096, torch.rand((4096, 65536, 2), device="cuda") * 2 - 1
     unit = 4096 * 65536 * 16
 libs = {"new": (new, plans(new)), "old": (old, plans(old))}
+if len(sys.argv) > 3 and sys.argv[3] == "swap":
+    libs = dict(reversed(list(libs.items())))
 s = torch.cuda.current_stream().cuda_stream
 def run(lib, ps, k):
     for j in range(k):
