@@ -102,7 +102,7 @@ class _Plan:
 
     def __del__(self):
         h, self._h = self._h, None
-        if h:
+        if h and lib is not None:      # module globals are already gone at interpreter shutdown
             lib().clfa_fft_destroy(h)
 
     def get_error(self):
@@ -196,7 +196,7 @@ class Clpconv:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib().clfa_pconv_destroy(h)
 
     def _report(self, e):
@@ -275,7 +275,7 @@ class Cldconv:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib().clfa_dconv_destroy(h)
 
     def cl_error_string(self, err):

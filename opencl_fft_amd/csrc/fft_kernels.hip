@@ -323,6 +323,9 @@ template <int LOGN> struct FourGeom {
   static constexpr int SL = (N1 * C1 > R2 * S2) ? N1 * C1 : R2 * S2;  // exchange elements per slice
   static constexpr int NCB = N2 / C1, NRB = N1 / R2;    // column blocks, row blocks per transform
   static constexpr int TABS = N1 / 2 + N2 / 2 + LO + HI;
+  // rows of the intermediate kept in LDS instead of the scratch (k_fft_4step, KL rows): row stride
+  // N2 + 16 elements puts the 4 rows a wave touches on 2 x 32 banks (the 2 passes 512 B need anyway)
+  static constexpr int RS = N2 + 16;
 };
 
 // phase 1 of one slice: column block cb of `src` (N1 x N2, row-major) ->
@@ -348,9 +351,10 @@ __device__ __forceinline__ void four_load1(cpx (&v)[16], const cpx *__restrict__
     }
   }
 }
-template <int LOGN, bool FWD>
+// KL > 0: rows k1 < KL of the result stay in LDS (`rows`, stride RS) and never reach the scratch
+template <int LOGN, bool FWD, int KL = 0>
 __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, int cb, int l, const cpx *tab1,
-                                           const cpx *tlo, const cpx *thi, cpx *sx) {
+                                           const cpx *tlo, const cpx *thi, cpx *sx, cpx *rows = nullptr) {
   using G = FourGeom<LOGN>;
   const int col = l % G::C1, tf = l / G::C1;
   const int n2 = cb * G::C1 + col;
@@ -366,7 +370,8 @@ __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, 
     const int ex = n2 * k1;  // < N
     cpx w = cmul(tlo[ex & (G::LO - 1)], thi[ex >> G::LOGLO]);
     if (!FWD) w.y = -w.y;
-    dst[(long)k1 * G::N2 + n2] = cmul(v[e], w);
+    if (e < KL / G::T1) rows[k1 * G::RS + n2] = cmul(v[e], w);   // k1 = tf + T1*e < KL, decided at compile time
+    else dst[(long)k1 * G::N2 + n2] = cmul(v[e], w);
   }
 }
 template <int LOGN, bool FWD, int SM>
@@ -393,6 +398,15 @@ __device__ __forceinline__ void four_load2(cpx (&v)[16], const cpx *__restrict__
   const cpx *p = src + (long)(rb * G::R2 + row) * G::N2 + tf;
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = SC1 ? ld_sc1(p + G::T2 * e) : p[G::T2 * e];
+}
+// the same row block out of the LDS-resident rows
+template <int LOGN>
+__device__ __forceinline__ void four_load2_rows(cpx (&v)[16], const cpx *rows, int rb, int l) {
+  using G = FourGeom<LOGN>;
+  const int tf = l % G::T2, row = l / G::T2;
+  const cpx *p = rows + (rb * G::R2 + row) * G::RS + tf;
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = p[G::T2 * e];
 }
 template <int LOGN, bool FWD, bool SCALE, int SM>
 __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, int rb, int l, const cpx *tab2,
@@ -443,13 +457,18 @@ __device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__
   four_body2<LOGN, FWD, SCALE, SM>(v, dst, rb, l, tab2, sx, read_done);
 }
 
-template <int LOGN, bool FWD, bool SCALE, int NSLICE, bool NT, bool PF = false>
+// ROWS (with PF): the first row block of every slice — rows k1 < KL = NSLICE * R2, 1/8 of the
+// intermediate for n = 65536 — stays in LDS between the phases instead of going through the scratch
+template <int LOGN, bool FWD, bool SCALE, int NSLICE, bool NT, bool PF = false, bool ROWS = false>
 __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ data, cpx *__restrict__ scratch,
                                                            const cpx *__restrict__ tabs_g, long batch) {
   using G = FourGeom<LOGN>;
+  static_assert(!ROWS || PF, "LDS-resident rows are wired into the prefetching form only");
   constexpr bool OPQ = CLFA_4STEP_OPAQUE;
+  constexpr int KL = ROWS ? NSLICE * G::R2 : 0;
   __shared__ cpx s_tabs[G::TABS];
   __shared__ cpx s_x[NSLICE * G::SL];
+  __shared__ cpx s_rows[ROWS ? KL * G::RS : 1];
   const int tid = threadIdx.x;
   for (int i = tid; i < G::TABS; i += 256 * NSLICE) s_tabs[i] = tabs_g[i];
   const cpx *tab1 = s_tabs, *tab2 = s_tabs + G::N1 / 2, *tlo = tab2 + G::N2 / 2, *thi = tlo + G::LO;
@@ -483,12 +502,16 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       // (counted s_waitcnt, see k_fft_lds), and consumed at the end of the iteration.
       cpx v[16], vn[16];
       four_load1<LOGN, NT ? 1 : 0>(v, x, slice, l);
+      // consumed before the loop: otherwise the wait for these loads is merged into the loop header,
+      // where it turns into vmcnt(0) on the back edge too and drains every iteration's scratch stores
+#pragma unroll
+      for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
 #pragma unroll 1
       for (int cb = slice; cb + NSLICE < G::NCB; cb += NSLICE) {
         int lo_ = l;   // opaque per iteration (see above)
         asm volatile("" : "+v"(lo_));
         four_load1<LOGN, NT ? 1 : 0>(vn, x, cb + NSLICE, lo_);
-        four_body1<LOGN, FWD>(v, mid, cb, lo_, tab1, tlo, thi, sx);
+        four_body1<LOGN, FWD, KL>(v, mid, cb, lo_, tab1, tlo, thi, sx, s_rows);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
@@ -498,10 +521,13 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       {
         int lo_ = l;
         asm volatile("" : "+v"(lo_));
-        four_body1<LOGN, FWD>(v, mid, G::NCB - NSLICE + slice, lo_, tab1, tlo, thi, sx);
+        four_body1<LOGN, FWD, KL>(v, mid, G::NCB - NSLICE + slice, lo_, tab1, tlo, thi, sx, s_rows);
       }
       __syncthreads();
-      four_load2<LOGN, false>(v, mid, slice, l);
+      if constexpr (ROWS) four_load2_rows<LOGN>(v, s_rows, slice, l);
+      else four_load2<LOGN, false>(v, mid, slice, l);
+#pragma unroll
+      for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
 #pragma unroll 1
       for (int rb = slice; rb + NSLICE < G::NRB; rb += NSLICE) {
         int lo_ = l;
@@ -559,6 +585,7 @@ struct FourVariant {
   bool nt;
   int wg_per_cu;
   bool pf;   // software prefetch of the next column / row block
+  bool rows = false;   // first row block of every slice stays in LDS
 };
 static FourVariant four_variant(int variant) {
   // {slices of 256 lanes per workgroup, non-temporal streaming, workgroups per CU, software prefetch}.
@@ -572,7 +599,8 @@ static FourVariant four_variant(int variant) {
     case 4: return {1, true, 2, false};
     case 5: return {4, true, 1, false};
     case 6: return {2, false, 2, false};
-    default: return {2, true, 1, true};  // 0: software prefetch, one workgroup per CU, 128 MiB of scratch
+    case 9: return {2, true, 1, true};   // the default's shape without the LDS-resident rows
+    default: return {2, true, 1, true, true};  // 0: software prefetch, one workgroup per CU, 128 MiB of scratch, LDS rows
   }
 }
 
@@ -601,6 +629,11 @@ static hipError_t launch_4step_v(int variant, cpx *data, cpx *scratch, const Fft
     return hipGetLastError();
   }
   if (batch < grid) grid = (int)batch;
+  if (v.rows) {
+    hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE, 2, true, true, true>), dim3(grid), dim3(512), 0, s, data, scratch,
+                       t.four, batch);
+    return hipGetLastError();
+  }
 #define CLFA_V(NS, NT, PF)                                                                                  \
   if (v.nslice == NS && v.nt == NT && v.pf == PF) {                                                         \
     hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE, NS, NT, PF>), dim3(grid), dim3(256 * NS), 0, s, data, \

@@ -49,7 +49,7 @@ hipError_t launch_fft_coop(int logn, bool fwd, bool scale, cpx *data, cpx *scrat
 hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s);
 // readiness-driven cooperative kernel (variant 8)
 constexpr int kVariantCoop2 = 8;
-constexpr int kVariantMax = 8;
+constexpr int kVariantMax = 9;   // 9: the default four-step shape without LDS-resident rows
 size_t coop2_ctl_bytes();
 hipError_t launch_fft_coop2(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
                             long batch, const DeviceInfo &di, hipStream_t s);

@@ -134,7 +134,7 @@ def test_cfft_device_resident_batch():
     assert np.max(np.abs(e_out / e_in - 1)) < 1e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_cfft_large_kernel_variants(variant):
     n, batch = 65536, 5
     x = util.lcg_complex(31 + variant, n * batch).reshape(batch, n)
