@@ -312,6 +312,9 @@ int fourstep_split(int logn, int *l1, int *l2, int *loglo) {
   return 0;
 }
 
+#ifndef CLFA_4STEP_RRB
+#define CLFA_4STEP_RRB 1   // register-resident row blocks per slice of the default n = 65536 kernel
+#endif
 template <int LOGN> struct FourGeom {
   static constexpr int LOGN1 = LOGN / 2, LOGN2 = LOGN - LOGN1;
   static constexpr int N = 1 << LOGN, N1 = 1 << LOGN1, N2 = 1 << LOGN2;
@@ -351,10 +354,18 @@ __device__ __forceinline__ void four_load1(cpx (&v)[16], const cpx *__restrict__
     }
   }
 }
-// KL > 0: rows k1 < KL of the result stay in LDS (`rows`, stride RS) and never reach the scratch
-template <int LOGN, bool FWD, int KL = 0>
+// A lane's results of one register-resident row set over the (8) column blocks of its slice: element
+// `it` (the slice's it-th column block) lives in floats 2*it, 2*it+1.  A native vector so that hipcc
+// indexes it with the uniform loop counter through s_set_gpr_idx (an array would go to scratch memory).
+typedef float vkeep __attribute__((ext_vector_type(16)));
+struct NoKeep {};
+// KL > 0: rows k1 < KL of the result stay in LDS (`rows`, stride RS) and never reach the scratch;
+// NE > 0: the next NE row sets (k1 = tf + T1*e, e = KL/T1 .. KL/T1 + NE - 1) stay in the lane's own
+// registers (`keep[e - KL/T1]`, element `it`) until phase 2 hands them over through LDS
+template <int LOGN, bool FWD, int KL = 0, int NE = 0, class Keep = NoKeep>
 __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, int cb, int l, const cpx *tab1,
-                                           const cpx *tlo, const cpx *thi, cpx *sx, cpx *rows = nullptr) {
+                                           const cpx *tlo, const cpx *thi, cpx *sx, cpx *rows = nullptr,
+                                           Keep *keep = nullptr, int it = 0) {
   using G = FourGeom<LOGN>;
   const int col = l % G::C1, tf = l / G::C1;
   const int n2 = cb * G::C1 + col;
@@ -370,8 +381,17 @@ __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, 
     const int ex = n2 * k1;  // < N
     cpx w = cmul(tlo[ex & (G::LO - 1)], thi[ex >> G::LOGLO]);
     if (!FWD) w.y = -w.y;
-    if (e < KL / G::T1) rows[k1 * G::RS + n2] = cmul(v[e], w);   // k1 = tf + T1*e < KL, decided at compile time
-    else dst[(long)k1 * G::N2 + n2] = cmul(v[e], w);
+    const cpx o = cmul(v[e], w);
+    if (e < KL / G::T1) {   // k1 = tf + T1*e < KL: decided at compile time
+      rows[k1 * G::RS + n2] = o;
+    } else if (e < KL / G::T1 + NE) {
+      if constexpr (NE > 0) {
+        keep[e - KL / G::T1][2 * it] = o.x;
+        keep[e - KL / G::T1][2 * it + 1] = o.y;
+      }
+    } else {
+      dst[(long)k1 * G::N2 + n2] = o;
+    }
   }
 }
 template <int LOGN, bool FWD, int SM>
@@ -466,6 +486,11 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
   static_assert(!ROWS || PF, "LDS-resident rows are wired into the prefetching form only");
   constexpr bool OPQ = CLFA_4STEP_OPAQUE;
   constexpr int KL = ROWS ? NSLICE * G::R2 : 0;
+  // ... and the next RRB row blocks of every slice in registers (n = 65536 only: one row set per row
+  // block, 8 column blocks per slice -> 16 VGPRs per row set; the 512-lane workgroup has 256 per lane)
+  constexpr int RRB = (ROWS && LOGN == 16 && NSLICE == 2) ? CLFA_4STEP_RRB : 0;
+  constexpr int NE = RRB * NSLICE;
+  static_assert(NE == 0 || (G::R2 == G::T1 && G::NCB / NSLICE == 8), "one row set per row block, 8 blocks per slice");
   __shared__ cpx s_tabs[G::TABS];
   __shared__ cpx s_x[NSLICE * G::SL];
   __shared__ cpx s_rows[ROWS ? KL * G::RS : 1];
@@ -501,6 +526,8 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       // The last block of each phase is peeled so that every prefetch is straight-line code
       // (counted s_waitcnt, see k_fft_lds), and consumed at the end of the iteration.
       cpx v[16], vn[16];
+      vkeep keep[NE > 0 ? NE : 1];
+      int it = 0;   // the slice's column-block counter: uniform, indexes `keep`
       four_load1<LOGN, NT ? 1 : 0>(v, x, slice, l);
       // consumed before the loop: otherwise the wait for these loads is merged into the loop header,
       // where it turns into vmcnt(0) on the back edge too and drains every iteration's scratch stores
@@ -511,7 +538,8 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
         int lo_ = l;   // opaque per iteration (see above)
         asm volatile("" : "+v"(lo_));
         four_load1<LOGN, NT ? 1 : 0>(vn, x, cb + NSLICE, lo_);
-        four_body1<LOGN, FWD, KL>(v, mid, cb, lo_, tab1, tlo, thi, sx, s_rows);
+        four_body1<LOGN, FWD, KL, NE>(v, mid, cb, lo_, tab1, tlo, thi, sx, s_rows, keep, it);
+        it++;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
@@ -521,15 +549,43 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       {
         int lo_ = l;
         asm volatile("" : "+v"(lo_));
-        four_body1<LOGN, FWD, KL>(v, mid, G::NCB - NSLICE + slice, lo_, tab1, tlo, thi, sx, s_rows);
+        four_body1<LOGN, FWD, KL, NE>(v, mid, G::NCB - NSLICE + slice, lo_, tab1, tlo, thi, sx, s_rows, keep,
+                                      G::NCB / NSLICE - 1);
       }
       __syncthreads();
       if constexpr (ROWS) four_load2_rows<LOGN>(v, s_rows, slice, l);
       else four_load2<LOGN, false>(v, mid, slice, l);
 #pragma unroll
       for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
+      int rb0 = slice;
+      if constexpr (NE > 0) {
+        // row blocks 1..RRB of each slice (rows 32.., alternating between the slices): every lane hands
+        // its register-resident results over through the LDS rows the previous blocks have just left
+#pragma unroll
+        for (int r = 0; r < RRB; r++) {
+          __syncthreads();
+          {
+            const int col = l % G::C1, tf = l / G::C1;
+#pragma unroll
+            for (int q = 0; q < NSLICE; q++) {
+              cpx *pr = s_rows + (q * G::R2 + tf) * G::RS + slice * G::C1 + col;
+#pragma unroll
+              for (int j = 0; j < G::NCB / NSLICE; j++)
+                pr[j * NSLICE * G::C1] = mk(keep[NSLICE * r + q][2 * j], keep[NSLICE * r + q][2 * j + 1]);
+            }
+          }
+          __syncthreads();
+          int lo_ = l;
+          asm volatile("" : "+v"(lo_));
+          four_load2_rows<LOGN>(vn, s_rows, slice, lo_);
+          four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, slice + NSLICE * r, lo_, tab2, sx);
+#pragma unroll
+          for (int e = 0; e < 16; e++) v[e] = vn[e];
+        }
+        rb0 = slice + NSLICE * RRB;
+      }
 #pragma unroll 1
-      for (int rb = slice; rb + NSLICE < G::NRB; rb += NSLICE) {
+      for (int rb = rb0; rb + NSLICE < G::NRB; rb += NSLICE) {
         int lo_ = l;
         asm volatile("" : "+v"(lo_));
         four_load2<LOGN, false>(vn, mid, rb + NSLICE, lo_);
