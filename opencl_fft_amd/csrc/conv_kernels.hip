@@ -142,13 +142,11 @@ __global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, co
       }
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) {
-        if (i2 == 0) {  // packed DC / Nyquist bin: (re*re, im*im)
-          s0.x += av[u].a.x * bv[u].a.x;
-          s0.y += av[u].a.y * bv[u].a.y;
-        } else {
-          s0 = cadd(s0, cmul(av[u].a, bv[u].a));
-        }
-        s1 = cadd(s1, cmul(av[u].b, bv[u].b));
+        cpx pr = cmul_plain(av[u].a, bv[u].a);
+        const bool dc = i2 == 0;  // packed DC / Nyquist bin: (re*re, im*im); a select keeps the loop body one block
+        pr = mk(dc ? av[u].a.x * bv[u].a.x : pr.x, dc ? av[u].a.y * bv[u].a.y : pr.y);
+        s0 = cadd(s0, pr);
+        s1 = cadd(s1, cmul_plain(av[u].b, bv[u].b));
       }
       fr += UNROLL;
       fr = fr < nparts ? fr : fr - nparts;
@@ -159,9 +157,9 @@ __global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, co
         s0.x += av.a.x * bv.a.x;
         s0.y += av.a.y * bv.a.y;
       } else {
-        s0 = cadd(s0, cmul(av.a, bv.a));
+        s0 = cadd(s0, cmul_plain(av.a, bv.a));
       }
-      s1 = cadd(s1, cmul(av.b, bv.b));
+      s1 = cadd(s1, cmul_plain(av.b, bv.b));
       fr = fr + 1 < nparts ? fr + 1 : 0;
     }
     cpx2 o;
@@ -391,13 +389,13 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
       }
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
-        if (k == 0 && tid == 0) {  // packed DC / Nyquist bin: (re*re, im*im)
-          s0[k].x += av[k].a.x * bv[k].a.x;
-          s0[k].y += av[k].a.y * bv[k].a.y;
-        } else {
-          s0[k] = cadd(s0[k], cmul(av[k].a, bv[k].a));
+        cpx pr = cmul_plain(av[k].a, bv[k].a);
+        if (k == 0) {  // lane 0: packed DC / Nyquist bin, (re*re, im*im) — a select, not a branch (a branch
+          const bool dc = tid == 0;   // splits the loop body and the streaming loads stop overlapping)
+          pr = mk(dc ? av[k].a.x * bv[k].a.x : pr.x, dc ? av[k].a.y * bv[k].a.y : pr.y);
         }
-        s1[k] = cadd(s1[k], cmul(av[k].b, bv[k].b));
+        s0[k] = cadd(s0[k], pr);
+        s1[k] = cadd(s1[k], cmul_plain(av[k].b, bv[k].b));
       }
       fr = fr + 1 < nparts ? fr + 1 : 0;
     }

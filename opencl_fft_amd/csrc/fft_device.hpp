@@ -27,21 +27,88 @@
 
 namespace clfa {
 
+// A complex value is a native 2-float vector on the device (and wherever clang compiles this
+// header): it lives in an aligned VGPR pair from the 8-byte load to the 8-byte store, and the
+// arithmetic below is CDNA's packed fp32 (v_pk_add/mul/fma_f32: both halves per instruction, the
+// same issue slot as a scalar op).  The multiplies and the +-i rotations use the instructions'
+// operand swizzles (op_sel: which half of a source feeds each half of the result; neg_lo/neg_hi)
+// through inline asm, because hipcc materialises such swizzles as v_mov / v_xor instead of folding
+// them: a complex multiply is 2 instructions instead of 4, add/sub (also with one operand times
+// +-i) 1 instead of 2.  g++ (tests/cpp/emulate_engine.cpp) sees a plain struct and scalar code.
+#if defined(__clang__)
+typedef float cpx __attribute__((ext_vector_type(2)));
+#define CLFA_VEC 1
+#else
 struct alignas(8) cpx {
   float x, y;
 };
+#define CLFA_VEC 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CLFA_PK 1
+#else
+#define CLFA_PK 0
+#endif
 
 CLFA_HD cpx mk(float x, float y) { cpx r; r.x = x; r.y = y; return r; }
+#if CLFA_VEC
+CLFA_HD cpx cadd(cpx a, cpx b) { return a + b; }
+CLFA_HD cpx csub(cpx a, cpx b) { return a - b; }
+CLFA_HD cpx cscale(cpx a, float s) { return a * s; }
+#else
 CLFA_HD cpx cadd(cpx a, cpx b) { return mk(a.x + b.x, a.y + b.y); }
 CLFA_HD cpx csub(cpx a, cpx b) { return mk(a.x - b.x, a.y - b.y); }
-CLFA_HD cpx cmul(cpx a, cpx b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 CLFA_HD cpx cscale(cpx a, float s) { return mk(a.x * s, a.y * s); }
+#endif
 CLFA_HD cpx cconj(cpx a) { return mk(a.x, -a.y); }
+// a * b, or a * conj(b)
+template <bool CONJ = false> CLFA_HD cpx cmulc(cpx a, cpx b) {
+#if CLFA_PK
+  cpx t, r;
+  if (!CONJ) {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                      // (ax bx, ax by)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"               // (-ay by, ay bx) + t
+        : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  } else {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));         // (ax bx, -ax by)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"                              // (ay by, ay bx) + t
+        : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  }
+  return r;
+#else
+  return CONJ ? mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y) : mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
+}
+CLFA_HD cpx cmul(cpx a, cpx b) { return cmulc<false>(a, b); }
+// the same without inline asm, for loops hipcc has to unroll with a run-time trip count: HIP treats
+// every asm statement as convergent, and a loop with a convergent operation is not given a remainder loop
+CLFA_HD cpx cmul_plain(cpx a, cpx b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // multiply by W_4^1: -i for a forward transform, +i for an inverse one
 template <bool FWD> CLFA_HD cpx rot4(cpx a) { return FWD ? mk(a.y, -a.x) : mk(-a.y, a.x); }
-// constant twiddle (c, -s) forward / (c, +s) inverse
+// x + rot4(y), x - rot4(y) in one instruction each
+template <bool FWD> CLFA_HD cpx add_rot(cpx x, cpx y) {
+#if CLFA_PK
+  cpx r;
+  if (FWD) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));  // (x.x + y.y, x.y - y.x)
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(x), "v"(y));      // (x.x - y.y, x.y + y.x)
+  return r;
+#else
+  return cadd(x, rot4<FWD>(y));
+#endif
+}
+template <bool FWD> CLFA_HD cpx sub_rot(cpx x, cpx y) { return add_rot<!FWD>(x, y); }
+// constant twiddle (c, -s) forward / (c, +s) inverse: a*c + rot4(a)*s
 template <bool FWD> CLFA_HD cpx ctw(cpx a, float c, float s) {
+#if CLFA_PK
+  const cpx k = mk(c, s);   // compile-time constants: an SGPR pair
+  cpx t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(k));                                      // (ax c, ay c)
+  if (FWD) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(k), "v"(t));  // (ay s, -ax s) + t
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(k), "v"(t));      // (-ay s, ax s) + t
+  return r;
+#else
   return FWD ? mk(a.x * c + a.y * s, a.y * c - a.x * s) : mk(a.x * c - a.y * s, a.y * c + a.x * s);
+#endif
 }
 
 constexpr float kC8 = 0.70710678118654752440f;   // cos(pi/4)
@@ -59,11 +126,20 @@ template <int U, int E, bool FWD> CLFA_HD void dft2(cpx (&v)[E], int u) {
 // natural-order 4-point DFT of (a0,a1,a2,a3) -> (y0,y1,y2,y3)
 template <bool FWD> CLFA_HD void bf4(cpx &a0, cpx &a1, cpx &a2, cpx &a3) {
   cpx s02 = cadd(a0, a2), d02 = csub(a0, a2);
-  cpx s13 = cadd(a1, a3), d13 = rot4<FWD>(csub(a1, a3));
+  cpx s13 = cadd(a1, a3), d13 = csub(a1, a3);
   a0 = cadd(s02, s13);
   a2 = csub(s02, s13);
-  a1 = cadd(d02, d13);
-  a3 = csub(d02, d13);
+  a1 = add_rot<FWD>(d02, d13);
+  a3 = sub_rot<FWD>(d02, d13);
+}
+// the same with rot4(a2) in place of a2 (the W_16^4 input of dft16)
+template <bool FWD> CLFA_HD void bf4_rot2(cpx &a0, cpx &a1, cpx &a2, cpx &a3) {
+  cpx s02 = add_rot<FWD>(a0, a2), d02 = sub_rot<FWD>(a0, a2);
+  cpx s13 = cadd(a1, a3), d13 = csub(a1, a3);
+  a0 = cadd(s02, s13);
+  a2 = csub(s02, s13);
+  a1 = add_rot<FWD>(d02, d13);
+  a3 = sub_rot<FWD>(d02, d13);
 }
 
 template <int U, int E, bool FWD> CLFA_HD void dft4(cpx (&v)[E], int u) {
@@ -78,14 +154,15 @@ template <int U, int E, bool FWD> CLFA_HD void dft8(cpx (&v)[E], int u) {
   bf4<FWD>(x[0], x[2], x[4], x[6]);  // b = 0: x[2*q0]
   bf4<FWD>(x[1], x[3], x[5], x[7]);  // b = 1: x[2*q0 + 1]
   x[3] = ctw<FWD>(x[3], kC8, kC8);   // W_8^1
-  x[5] = rot4<FWD>(x[5]);            // W_8^2
   x[7] = ctw<FWD>(x[7], -kC8, kC8);  // W_8^3
-#pragma unroll
-  for (int q0 = 0; q0 < 4; q0++) {
-    cpx a = x[2 * q0], b = x[2 * q0 + 1];
-    v[u + U * q0] = cadd(a, b);
-    v[u + U * (q0 + 4)] = csub(a, b);
-  }
+  v[u] = cadd(x[0], x[1]);
+  v[u + U * 4] = csub(x[0], x[1]);
+  v[u + U * 1] = cadd(x[2], x[3]);
+  v[u + U * 5] = csub(x[2], x[3]);
+  v[u + U * 2] = add_rot<FWD>(x[4], x[5]);   // W_8^2 = rot4, folded into the butterfly
+  v[u + U * 6] = sub_rot<FWD>(x[4], x[5]);
+  v[u + U * 3] = cadd(x[6], x[7]);
+  v[u + U * 7] = csub(x[6], x[7]);
 }
 
 // 16 = 4 x 4: t = 4a + b, q = q0 + 4*q1
@@ -100,14 +177,15 @@ template <int U, int E, bool FWD> CLFA_HD void dft16(cpx (&v)[E], int u) {
   x[4 + 2] = ctw<FWD>(x[4 + 2], kC8, kC8);      // 2
   x[4 + 3] = ctw<FWD>(x[4 + 3], kS16, kC16);    // 3
   x[8 + 1] = ctw<FWD>(x[8 + 1], kC8, kC8);      // 2
-  x[8 + 2] = rot4<FWD>(x[8 + 2]);               // 4
+  //                                               4: rot4, folded into bf4_rot2 below
   x[8 + 3] = ctw<FWD>(x[8 + 3], -kC8, kC8);     // 6
   x[12 + 1] = ctw<FWD>(x[12 + 1], kS16, kC16);  // 3
   x[12 + 2] = ctw<FWD>(x[12 + 2], -kC8, kC8);   // 6
   x[12 + 3] = ctw<FWD>(x[12 + 3], -kC16, -kS16);// 9
 #pragma unroll
   for (int q0 = 0; q0 < 4; q0++) {
-    bf4<FWD>(x[4 * q0], x[4 * q0 + 1], x[4 * q0 + 2], x[4 * q0 + 3]);  // -> q1
+    if (q0 == 2) bf4_rot2<FWD>(x[8], x[9], x[10], x[11]);
+    else bf4<FWD>(x[4 * q0], x[4 * q0 + 1], x[4 * q0 + 2], x[4 * q0 + 3]);  // -> q1
 #pragma unroll
     for (int q1 = 0; q1 < 4; q1++) v[u + U * (q0 + 4 * q1)] = x[4 * q0 + q1];
   }
@@ -184,6 +262,23 @@ template <int LOGN, bool FWD, int LOGLO> CLFA_HD cpx tw_lookup(const TwoLevelTab
   if (!FWD) w.y = -w.y;
   return w;
 }
+// v * W_n^k for a forward transform, v * conj(W_n^k) for an inverse one (the conjugation rides on
+// the multiply's operand modifiers)
+template <int LOGN, bool FWD, class Tab> CLFA_HD cpx cmul_tw(cpx v, const Tab &tab, int k) {
+  if constexpr (LOGN == 0) return v;
+  constexpr int half = (1 << LOGN) >> 1;
+  cpx r = cmulc<!FWD>(v, tab[k & (half - 1)]);
+  if (k & half) r = mk(-r.x, -r.y);
+  return r;
+}
+// full table W_n^k, k < n (forward sign): no half-table sign logic (3-4 VALU per lookup); used where LDS allows
+struct FullTab {
+  const cpx *p;
+};
+template <int LOGN, bool FWD> CLFA_HD cpx cmul_tw(cpx v, const FullTab &tab, int k) { return cmulc<!FWD>(v, tab.p[k]); }
+template <int LOGN, bool FWD, int LOGLO> CLFA_HD cpx cmul_tw(cpx v, const TwoLevelTab<LOGLO> &tab, int k) {
+  return cmulc<!FWD>(v, cmul(tab.hi[k >> LOGLO], tab.lo[k & ((1 << LOGLO) - 1)]));
+}
 
 // One pass on the registers of lane `tid`: input twiddles then U butterflies.
 template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
@@ -197,7 +292,7 @@ CLFA_HD void pass_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
 #pragma unroll
       for (int t = 1; t < R; t++) {
         int k = (jm * t) << (LOGN - LOGNS - LOGR);
-        v[u + U * t] = cmul(v[u + U * t], tw_lookup<LOGN, FWD>(tab, k));
+        v[u + U * t] = cmul_tw<LOGN, FWD>(v[u + U * t], tab, k);
 #if defined(__HIP_DEVICE_COMPILE__)
         // with 32 points per lane hipcc otherwise hoists every table read of the pass ahead of
         // the multiplies (100+ live VGPRs of twiddles) and spills: fence the scheduler every 4
@@ -295,7 +390,7 @@ CLFA_HD void dif_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
 #pragma unroll
       for (int q = 1; q < R; q++) {
         int k = (jm * q) << (LOGN - LOGNS - LOGR);
-        v[u + U * q] = cmul(v[u + U * q], tw_lookup<LOGN, FWD>(tab, k));
+        v[u + U * q] = cmul_tw<LOGN, FWD>(v[u + U * q], tab, k);
       }
     }
   }
@@ -449,8 +544,8 @@ CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, cons
     }
 #pragma unroll
     for (int t = 1; t < R; t++) {
-      v[u + U * t] = cmul(v[u + U * t], tw_lookup<LOGN, FWD>(tab, j * t));
-      v[u + U / 2 + U * t] = cmul(v[u + U / 2 + U * t], tw_lookup<LOGN, FWD>(tab, jp * t));
+      v[u + U * t] = cmul_tw<LOGN, FWD>(v[u + U * t], tab, j * t);
+      v[u + U / 2 + U * t] = cmul_tw<LOGN, FWD>(v[u + U / 2 + U * t], tab, jp * t);
     }
   }
 #pragma unroll
@@ -516,8 +611,8 @@ CLFA_HD void pass_first_paired(cpx (&v)[1 << LOGE], int tid, const cpx (&oi)[(1 
     const int jp = j == 0 ? NB / 2 : NB - j;
 #pragma unroll
     for (int q = 1; q < R; q++) {
-      v[u + U * q] = cmul(v[u + U * q], tw_lookup<LOGN, FWD>(tab, j * q));
-      v[u + U / 2 + U * q] = cmul(v[u + U / 2 + U * q], tw_lookup<LOGN, FWD>(tab, jp * q));
+      v[u + U * q] = cmul_tw<LOGN, FWD>(v[u + U * q], tab, j * q);
+      v[u + U / 2 + U * q] = cmul_tw<LOGN, FWD>(v[u + U / 2 + U * q], tab, jp * q);
     }
   }
 }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     const long b = g * FPW + f;
     lds_fft_load<LOGN, MODE>(v, data + (b < batch ? b : batch - 1) * (long)N, t);
 #pragma unroll
-    for (int e = 0; e < E; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
+    for (int e = 0; e < E; e++) asm volatile("" : "+v"(v[e]));
   }
   const int t_invariant = t;
 #pragma unroll 1
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     if constexpr (G::PREFETCH) {
 #pragma unroll
       for (int e = 0; e < E; e++) {
-        asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
+        asm volatile("" : "+v"(vn[e]));
         v[e] = vn[e];
       }
     } else {
@@ -313,7 +313,7 @@ int fourstep_split(int logn, int *l1, int *l2, int *loglo) {
 }
 
 #ifndef CLFA_4STEP_RRB
-#define CLFA_4STEP_RRB 1   // register-resident row blocks per slice of the default n = 65536 kernel
+#define CLFA_4STEP_RRB 5   // register-resident row blocks per slice of the default n = 65536 kernel
 #endif
 template <int LOGN> struct FourGeom {
   static constexpr int LOGN1 = LOGN / 2, LOGN2 = LOGN - LOGN1;
@@ -331,28 +331,45 @@ template <int LOGN> struct FourGeom {
   static constexpr int RS = N2 + 16;
 };
 
+// Wave-uniform base pointers kept in SGPR pairs.  A global access whose address is
+// (uniform 64-bit base) + (32-bit lane offset) uses the saddr form  global_load v, v_off, s[b:b+1]:
+// no 64-bit VALU add with carry (and its hazard nops) per access.  The base goes through an opaque
+// SGPR integer so that hipcc cannot fold the lane part into it, and comes back as a global-memory
+// (address space 1) pointer so that the access is not demoted to a flat one.
+typedef __attribute__((address_space(1))) unsigned long long *gptr;
+typedef const __attribute__((address_space(1))) unsigned long long *gcptr;
+__device__ __forceinline__ gptr sgpr_base(const cpx *p) {
+  unsigned long long b = reinterpret_cast<unsigned long long>(p);
+  asm volatile("" : "+s"(b));
+  return reinterpret_cast<gptr>(b);
+}
+// streaming mode: 0 plain, 1 non-temporal, 2 system scope (sc0 sc1), 3 agent scope (sc1: bypasses the CU's L1)
+template <int SM> __device__ __forceinline__ cpx ld_g(gcptr p) {
+  unsigned long long raw;
+  if constexpr (SM == 1) raw = __builtin_nontemporal_load(p);
+  else if constexpr (SM == 2) raw = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else if constexpr (SM == 3) raw = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else raw = *p;
+  return *reinterpret_cast<const cpx *>(&raw);
+}
+template <int SM> __device__ __forceinline__ void st_g(gptr p, cpx v) {
+  const unsigned long long raw = *reinterpret_cast<const unsigned long long *>(&v);
+  if constexpr (SM == 1) __builtin_nontemporal_store(raw, p);
+  else if constexpr (SM == 2) __hip_atomic_store(p, raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else *p = raw;
+}
+
 // phase 1 of one slice: column block cb of `src` (N1 x N2, row-major) ->
 // N1-point FFT down the columns, times W_N^(n2*k1), stored to dst[k1][n2].
 // streaming mode of the input loads / output stores: 0 plain, 1 non-temporal, 2 system scope (sc0 sc1)
 template <int LOGN, int SM>
 __device__ __forceinline__ void four_load1(cpx (&v)[16], const cpx *__restrict__ src, int cb, int l) {
   using G = FourGeom<LOGN>;
-  const int col = l % G::C1, tf = l / G::C1;
-  const int n2 = cb * G::C1 + col;
+  const unsigned col = (unsigned)l % G::C1, tf = ((unsigned)l & (G::SLICE - 1)) / G::C1;
+  const unsigned lane = tf * G::N2 + col;
+  const cpx *base = src + cb * G::C1;   // cb is wave-uniform
 #pragma unroll
-  for (int e = 0; e < 16; e++) {
-    const cpx *p = src + (long)(tf + G::T1 * e) * G::N2 + n2;
-    if constexpr (SM == 1) {
-      const unsigned long long raw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
-      v[e] = *reinterpret_cast<const cpx *>(&raw);
-    } else if constexpr (SM == 2) {
-      const unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      v[e] = *reinterpret_cast<const cpx *>(&raw);
-    } else {
-      v[e] = *p;
-    }
-  }
+  for (int e = 0; e < 16; e++) v[e] = ld_g<SM>(sgpr_base(base + (long)(G::T1 * e) * G::N2) + lane);
 }
 // A lane's results of one register-resident row set over the (8) column blocks of its slice: element
 // `it` (the slice's it-th column block) lives in floats 2*it, 2*it+1.  A native vector so that hipcc
@@ -362,12 +379,12 @@ struct NoKeep {};
 // KL > 0: rows k1 < KL of the result stay in LDS (`rows`, stride RS) and never reach the scratch;
 // NE > 0: the next NE row sets (k1 = tf + T1*e, e = KL/T1 .. KL/T1 + NE - 1) stay in the lane's own
 // registers (`keep[e - KL/T1]`, element `it`) until phase 2 hands them over through LDS
-template <int LOGN, bool FWD, int KL = 0, int NE = 0, class Keep = NoKeep>
-__device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, int cb, int l, const cpx *tab1,
+template <int LOGN, bool FWD, int KL = 0, int NE = 0, class Keep = NoKeep, class Tab = const cpx *>
+__device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, int cb, int l, const Tab &tab1,
                                            const cpx *tlo, const cpx *thi, cpx *sx, cpx *rows = nullptr,
                                            Keep *keep = nullptr, int it = 0) {
   using G = FourGeom<LOGN>;
-  const int col = l % G::C1, tf = l / G::C1;
+  const int col = (unsigned)l % G::C1, tf = ((unsigned)l & (G::SLICE - 1)) / G::C1;
   const int n2 = cb * G::C1 + col;
   pass_compute<G::LOGN1, 4, 0, FWD>(v, tf, tab1);
   __syncthreads();
@@ -379,9 +396,7 @@ __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, 
   for (int e = 0; e < 16; e++) {
     const int k1 = tf + G::T1 * e;
     const int ex = n2 * k1;  // < N
-    cpx w = cmul(tlo[ex & (G::LO - 1)], thi[ex >> G::LOGLO]);
-    if (!FWD) w.y = -w.y;
-    const cpx o = cmul(v[e], w);
+    const cpx o = cmulc<!FWD>(v[e], cmul(tlo[ex & (G::LO - 1)], thi[ex >> G::LOGLO]));
     if (e < KL / G::T1) {   // k1 = tf + T1*e < KL: decided at compile time
       rows[k1 * G::RS + n2] = o;
     } else if (e < KL / G::T1 + NE) {
@@ -390,7 +405,7 @@ __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, 
         keep[e - KL / G::T1][2 * it + 1] = o.y;
       }
     } else {
-      dst[(long)k1 * G::N2 + n2] = o;
+      st_g<0>(sgpr_base(dst + (long)(G::T1 * e) * G::N2 + cb * G::C1) + (unsigned)(tf * G::N2 + col), o);
     }
   }
 }
@@ -414,10 +429,10 @@ __device__ __forceinline__ cpx ld_sc1(const cpx *p) {
 template <int LOGN, bool SC1>
 __device__ __forceinline__ void four_load2(cpx (&v)[16], const cpx *__restrict__ src, int rb, int l) {
   using G = FourGeom<LOGN>;
-  const int tf = l % G::T2, row = l / G::T2;
-  const cpx *p = src + (long)(rb * G::R2 + row) * G::N2 + tf;
+  const int tf = (unsigned)l % G::T2, row = ((unsigned)l & (G::SLICE - 1)) / G::T2;
+  const gcptr p = sgpr_base(src + (long)(rb * G::R2) * G::N2) + (unsigned)(row * G::N2 + tf);   // rb is wave-uniform
 #pragma unroll
-  for (int e = 0; e < 16; e++) v[e] = SC1 ? ld_sc1(p + G::T2 * e) : p[G::T2 * e];
+  for (int e = 0; e < 16; e++) v[e] = ld_g<SC1 ? 3 : 0>(p + G::T2 * e);
 }
 // the same row block out of the LDS-resident rows
 template <int LOGN>
@@ -428,8 +443,8 @@ __device__ __forceinline__ void four_load2_rows(cpx (&v)[16], const cpx *rows, i
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = p[G::T2 * e];
 }
-template <int LOGN, bool FWD, bool SCALE, int SM>
-__device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, int rb, int l, const cpx *tab2,
+template <int LOGN, bool FWD, bool SCALE, int SM, class Tab = const cpx *>
+__device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, int rb, int l, const Tab &tab2,
                                            cpx *sx, unsigned *read_done = nullptr) {
   using G = FourGeom<LOGN>;
   {
@@ -445,26 +460,19 @@ __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, 
   }
   // the last pass runs with rows on the fast lane index so that the transposed
   // store below is contiguous across lanes
-  const int row = l % G::R2, tf = l / G::R2;
+  // (masked: the lane index passes through an opaque move in the callers; its range has to be visible
+  // for the 32-bit lane offsets of the saddr addressing)
+  const int row = (unsigned)l % G::R2, tf = ((unsigned)l & (G::SLICE - 1)) / G::R2;
   const cpx *xr = sx + row * G::S2;
   pass_gather_padded<G::LOGN2, 4>(v, tf, xr);
   pass_compute<G::LOGN2, 4, 4, FWD>(v, tf, tab2);
-  const int k1 = rb * G::R2 + row;
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const int k2 = tf + G::T2 * e;
     cpx o = v[e];
     if constexpr (SCALE) o = cscale(o, 1.0f / (float)G::N);
-    cpx *p = dst + (long)k2 * G::N1 + k1;
-    if constexpr (SM == 1) {
-      __builtin_nontemporal_store(*reinterpret_cast<unsigned long long *>(&o),
-                                  reinterpret_cast<unsigned long long *>(p));
-    } else if constexpr (SM == 2) {
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), *reinterpret_cast<unsigned long long *>(&o),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-      *p = o;
-    }
+    (void)k2;
+    st_g<SM>(sgpr_base(dst + (long)(G::T2 * e) * G::N1 + rb * G::R2) + (unsigned)(tf * G::N1 + row), o);
   }
 }
 // phase 2 of one slice: row block rb of `src` (rows k1, contiguous n2) ->
@@ -494,10 +502,23 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
   __shared__ cpx s_tabs[G::TABS];
   __shared__ cpx s_x[NSLICE * G::SL];
   __shared__ cpx s_rows[ROWS ? KL * G::RS : 1];
+  // full W_N1 / W_N2 tables for the pass twiddles of the prefetching form (no half-table sign logic)
+  __shared__ cpx s_full[PF ? G::N1 + G::N2 : 1];
   const int tid = threadIdx.x;
   for (int i = tid; i < G::TABS; i += 256 * NSLICE) s_tabs[i] = tabs_g[i];
   const cpx *tab1 = s_tabs, *tab2 = s_tabs + G::N1 / 2, *tlo = tab2 + G::N2 / 2, *thi = tlo + G::LO;
-  const int slice = tid / G::SLICE, l = tid % G::SLICE;
+  if constexpr (PF) {
+    for (int i = tid; i < G::N1 + G::N2; i += 256 * NSLICE) {
+      const bool second = i >= G::N1;
+      const int k = second ? i - G::N1 : i, h = (second ? G::N2 : G::N1) / 2;
+      const cpx w = tabs_g[(second ? G::N1 / 2 : 0) + (k & (h - 1))];
+      s_full[i] = (k & h) ? mk(-w.x, -w.y) : w;
+    }
+  }
+  const FullTab ftab1{s_full}, ftab2{s_full + G::N1};
+  // the slice index is wave-uniform (a slice is 4 whole waves): say so, so that block indices and the
+  // pointers derived from them stay in SGPRs
+  const int slice = __builtin_amdgcn_readfirstlane(tid / G::SLICE), l = tid % G::SLICE;
   cpx *sx = s_x + slice * G::SL;
   cpx *mid = scratch + (long)blockIdx.x * G::N;
   __syncthreads();
@@ -532,31 +553,31 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       // consumed before the loop: otherwise the wait for these loads is merged into the loop header,
       // where it turns into vmcnt(0) on the back edge too and drains every iteration's scratch stores
 #pragma unroll
-      for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
+      for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e]));
 #pragma unroll 1
       for (int cb = slice; cb + NSLICE < G::NCB; cb += NSLICE) {
         int lo_ = l;   // opaque per iteration (see above)
         asm volatile("" : "+v"(lo_));
         four_load1<LOGN, NT ? 1 : 0>(vn, x, cb + NSLICE, lo_);
-        four_body1<LOGN, FWD, KL, NE>(v, mid, cb, lo_, tab1, tlo, thi, sx, s_rows, keep, it);
+        four_body1<LOGN, FWD, KL, NE>(v, mid, cb, lo_, ftab1, tlo, thi, sx, s_rows, keep, it);
         it++;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-          asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
+          asm volatile("" : "+v"(vn[e]));
           v[e] = vn[e];
         }
       }
       {
         int lo_ = l;
         asm volatile("" : "+v"(lo_));
-        four_body1<LOGN, FWD, KL, NE>(v, mid, G::NCB - NSLICE + slice, lo_, tab1, tlo, thi, sx, s_rows, keep,
+        four_body1<LOGN, FWD, KL, NE>(v, mid, G::NCB - NSLICE + slice, lo_, ftab1, tlo, thi, sx, s_rows, keep,
                                       G::NCB / NSLICE - 1);
       }
       __syncthreads();
       if constexpr (ROWS) four_load2_rows<LOGN>(v, s_rows, slice, l);
       else four_load2<LOGN, false>(v, mid, slice, l);
 #pragma unroll
-      for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e].x), "+v"(v[e].y));
+      for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e]));
       int rb0 = slice;
       if constexpr (NE > 0) {
         // row blocks 1..RRB of each slice (rows 32.., alternating between the slices): every lane hands
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
           int lo_ = l;
           asm volatile("" : "+v"(lo_));
           four_load2_rows<LOGN>(vn, s_rows, slice, lo_);
-          four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, slice + NSLICE * r, lo_, tab2, sx);
+          four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, slice + NSLICE * r, lo_, ftab2, sx);
 #pragma unroll
           for (int e = 0; e < 16; e++) v[e] = vn[e];
         }
@@ -589,17 +610,17 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
         int lo_ = l;
         asm volatile("" : "+v"(lo_));
         four_load2<LOGN, false>(vn, mid, rb + NSLICE, lo_);
-        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, rb, lo_, tab2, sx);
+        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, rb, lo_, ftab2, sx);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-          asm volatile("" : "+v"(vn[e].x), "+v"(vn[e].y));
+          asm volatile("" : "+v"(vn[e]));
           v[e] = vn[e];
         }
       }
       {
         int lo_ = l;
         asm volatile("" : "+v"(lo_));
-        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, G::NRB - NSLICE + slice, lo_, tab2, sx);
+        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, G::NRB - NSLICE + slice, lo_, ftab2, sx);
       }
       __syncthreads();
     }
@@ -1254,9 +1275,7 @@ __global__ __launch_bounds__(256) void k_big_cols(const cpx *__restrict__ data, 
   for (int e = 0; e < 16; e++) {
     const int k1 = tf + T1 * e;
     const int ex = n2 * k1;  // < n <= 2^24
-    cpx w = cmul(tlo[ex & mlo], thi[ex >> loglo]);
-    if (!FWD) w.y = -w.y;
-    scratch[base + ((long)k1 << logn2)] = cmul(v[e], w);
+    scratch[base + ((long)k1 << logn2)] = cmulc<!FWD>(v[e], cmul(tlo[ex & mlo], thi[ex >> loglo]));
   }
 }
 
