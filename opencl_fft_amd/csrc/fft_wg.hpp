@@ -44,9 +44,10 @@ template <int LOGN> struct LdsGeom {
   // 16 points per lane.  (32 points per lane with radix-32 passes was measured for n = 8192:
   // slower — 4.08 vs 4.38 TB/s — so the radix-32 butterfly stays in fft_device.hpp unused here.)
   static constexpr int LOGE = cmin(4, LOGN);
-  // n = 8192 runs WITHOUT the register prefetch but capped at 128 VGPRs, so that two 512-lane
-  // workgroups share a CU (LDS 71 KiB each thanks to the two-level twiddle table)
-  static constexpr bool PREFETCH = LOGN <= 12;
+  // n = 8192 is capped at 128 VGPRs so that two 512-lane workgroups share a CU (LDS 71 KiB each thanks
+  // to the two-level twiddle table); with packed arithmetic the register prefetch fits under the cap
+  // (28 bytes of spill in c2c / r2c) and is worth 5 % (c2c 4.99 -> 5.22 TB/s, interleaved A/B)
+  static constexpr bool PREFETCH = LOGN <= 13;
   static constexpr int MIN_WAVES = LOGN >= 13 ? 4 : 1;
   static constexpr int E = 1 << LOGE;
   static constexpr int T = N / E;                       // lanes per transform
