@@ -371,14 +371,16 @@ __device__ __forceinline__ void four_load1(cpx (&v)[16], const cpx *__restrict__
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = ld_g<SM>(sgpr_base(base + (long)(G::T1 * e) * G::N2) + lane);
 }
-// A lane's results of one register-resident row set over the (8) column blocks of its slice: element
-// `it` (the slice's it-th column block) lives in floats 2*it, 2*it+1.  A native vector so that hipcc
-// indexes it with the uniform loop counter through s_set_gpr_idx (an array would go to scratch memory).
+// A lane's results of one register-resident row block over the column blocks of its slice (8 values
+// for every n: n = 65536 has 1 row set per block x 8 column blocks, 32768 2 x 4, 16384 4 x 2).  A native
+// vector so that hipcc indexes it with the uniform loop counter through s_set_gpr_idx (an array would
+// go to scratch memory).
 typedef float vkeep __attribute__((ext_vector_type(16)));
 struct NoKeep {};
-// KL > 0: rows k1 < KL of the result stay in LDS (`rows`, stride RS) and never reach the scratch;
-// NE > 0: the next NE row sets (k1 = tf + T1*e, e = KL/T1 .. KL/T1 + NE - 1) stay in the lane's own
-// registers (`keep[e - KL/T1]`, element `it`) until phase 2 hands them over through LDS
+// KL > 0: rows k1 < KL of the result (the first KL / R2 row blocks) stay in LDS (`rows`, stride RS) and
+// never reach the scratch; NE > 0: the next NE row blocks stay in the lane's own registers
+// (`keep[block]`, element it * EB + eb for the slice's it-th column block) until phase 2 hands them
+// over through LDS
 template <int LOGN, bool FWD, int KL = 0, int NE = 0, class Keep = NoKeep, class Tab = const cpx *>
 __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, int cb, int l, const Tab &tab1,
                                            const cpx *tlo, const cpx *thi, cpx *sx, cpx *rows = nullptr,
@@ -397,12 +399,15 @@ __device__ __forceinline__ void four_body1(cpx (&v)[16], cpx *__restrict__ dst, 
     const int k1 = tf + G::T1 * e;
     const int ex = n2 * k1;  // < N
     const cpx o = cmulc<!FWD>(v[e], cmul(tlo[ex & (G::LO - 1)], thi[ex >> G::LOGLO]));
-    if (e < KL / G::T1) {   // k1 = tf + T1*e < KL: decided at compile time
+    // row k1 = tf + T1*e belongs to row block e / EB (EB row sets per block): all decided at compile time
+    constexpr int EB = G::R2 / G::T1;
+    const int blk = e / EB, eb = e % EB;
+    if (blk < KL / G::R2) {
       rows[k1 * G::RS + n2] = o;
-    } else if (e < KL / G::T1 + NE) {
+    } else if (blk < KL / G::R2 + NE) {
       if constexpr (NE > 0) {
-        keep[e - KL / G::T1][2 * it] = o.x;
-        keep[e - KL / G::T1][2 * it + 1] = o.y;
+        keep[blk - KL / G::R2][2 * (it * EB + eb)] = o.x;
+        keep[blk - KL / G::R2][2 * (it * EB + eb) + 1] = o.y;
       }
     } else {
       st_g<0>(sgpr_base(dst + (long)(G::T1 * e) * G::N2 + cb * G::C1) + (unsigned)(tf * G::N2 + col), o);
@@ -494,11 +499,13 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
   static_assert(!ROWS || PF, "LDS-resident rows are wired into the prefetching form only");
   constexpr bool OPQ = CLFA_4STEP_OPAQUE;
   constexpr int KL = ROWS ? NSLICE * G::R2 : 0;
-  // ... and the next RRB row blocks of every slice in registers (n = 65536 only: one row set per row
-  // block, 8 column blocks per slice -> 16 VGPRs per row set; the 512-lane workgroup has 256 per lane)
-  constexpr int RRB = (ROWS && LOGN == 16 && NSLICE == 2) ? CLFA_4STEP_RRB : 0;
+  // ... and the next RRB row blocks of every slice in registers (16 VGPRs per block; the 512-lane
+  // workgroup has 256 per lane): 5 of the remaining 7 for n = 65536, all of them for 32768 (3) and
+  // 16384 (1), whose scratch is then never touched
+  constexpr int RRB = !(ROWS && NSLICE == 2) ? 0 : LOGN == 16 ? CLFA_4STEP_RRB : G::NRB / NSLICE - 1;
   constexpr int NE = RRB * NSLICE;
-  static_assert(NE == 0 || (G::R2 == G::T1 && G::NCB / NSLICE == 8), "one row set per row block, 8 blocks per slice");
+  constexpr int EB = G::R2 / G::T1, NIT = G::NCB / NSLICE;
+  static_assert(NE == 0 || EB * NIT == 8, "a row block is 8 values per lane");
   __shared__ cpx s_tabs[G::TABS];
   __shared__ cpx s_x[NSLICE * G::SL];
   __shared__ cpx s_rows[ROWS ? KL * G::RS : 1];
@@ -589,10 +596,13 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
             const int col = l % G::C1, tf = l / G::C1;
 #pragma unroll
             for (int q = 0; q < NSLICE; q++) {
-              cpx *pr = s_rows + (q * G::R2 + tf) * G::RS + slice * G::C1 + col;
 #pragma unroll
-              for (int j = 0; j < G::NCB / NSLICE; j++)
-                pr[j * NSLICE * G::C1] = mk(keep[NSLICE * r + q][2 * j], keep[NSLICE * r + q][2 * j + 1]);
+              for (int eb = 0; eb < EB; eb++) {
+                cpx *pr = s_rows + (q * G::R2 + tf + G::T1 * eb) * G::RS + slice * G::C1 + col;
+#pragma unroll
+                for (int j = 0; j < NIT; j++)
+                  pr[j * NSLICE * G::C1] = mk(keep[NSLICE * r + q][2 * (j * EB + eb)], keep[NSLICE * r + q][2 * (j * EB + eb) + 1]);
+              }
             }
           }
           __syncthreads();

@@ -41,7 +41,7 @@ def main():
         f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
         ms = timeit(alt(f, i, x, batch), iters=20)
         print("r2c/c2r %d x %d: %.3f ms alg %.2f TB/s" % (size, batch, ms, batch * size * 8 / ms / 1e9))
-    for n, batch in [(1024, 262144), (4096, 65536), (8192, 32768), (256, 1 << 20)]:
+    for n, batch in [(1024, 262144), (4096, 65536), (8192, 32768), (256, 1 << 20), (16384, 16384), (32768, 8192)]:
         x = torch.rand((batch, n, 2), device="cuda") * 2 - 1
         f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
         ms = timeit(alt(f, i, x, batch), iters=20)
