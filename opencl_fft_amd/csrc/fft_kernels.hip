@@ -18,6 +18,8 @@
 
 #include "fft_wg.hpp"
 
+#include <type_traits>
+
 namespace clfa {
 
 // ---------------------------------------------------------------------------------
@@ -448,9 +450,14 @@ __device__ __forceinline__ void four_load2_rows(cpx (&v)[16], const cpx *rows, i
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = p[G::T2 * e];
 }
-template <int LOGN, bool FWD, bool SCALE, int SM, class Tab = const cpx *>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `between` runs between the block's two barriers (after every wave has passed the first one): the
+// register-resident row blocks are handed over there at no extra barrier
+template <int LOGN, bool FWD, bool SCALE, int SM, class Tab = const cpx *, class Hook = NoHook>
 __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, int rb, int l, const Tab &tab2,
-                                           cpx *sx, unsigned *read_done = nullptr) {
+                                           cpx *sx, unsigned *read_done = nullptr, Hook between = Hook()) {
   using G = FourGeom<LOGN>;
   {
     const int tf = l % G::T2, row = l / G::T2;
@@ -458,6 +465,7 @@ __device__ __forceinline__ void four_body2(cpx (&v)[16], cpx *__restrict__ dst, 
     __syncthreads();
     cpx *xr = sx + row * G::S2;
     pass_scatter_padded<G::LOGN2, 4, 0>(v, tf, xr);
+    between();
     __syncthreads();
     // every lane has consumed its loads from the scratch: the slot may be reused
     if (read_done != nullptr && l == 0)
@@ -587,32 +595,49 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e]));
       int rb0 = slice;
       if constexpr (NE > 0) {
-        // row blocks 1..RRB of each slice (rows 32.., alternating between the slices): every lane hands
-        // its register-resident results over through the LDS rows the previous blocks have just left
+        // Row blocks 1..RRB of each slice (rows 32.., alternating between the slices): every lane hands
+        // its register-resident results over through the LDS rows the previous blocks have just left.
+        // Block r+1 is dumped between the two barriers of block r-1's passes: at the first of them every
+        // wave has already taken block r out of those rows (its load precedes the passes in program
+        // order), the second publishes the dump — no barrier of its own except for the first block.
+        auto dump = [&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          const int col = l % G::C1, tf = l / G::C1;
 #pragma unroll
-        for (int r = 0; r < RRB; r++) {
-          __syncthreads();
-          {
-            const int col = l % G::C1, tf = l / G::C1;
+          for (int q = 0; q < NSLICE; q++) {
 #pragma unroll
-            for (int q = 0; q < NSLICE; q++) {
+            for (int eb = 0; eb < EB; eb++) {
+              cpx *pr = s_rows + (q * G::R2 + tf + G::T1 * eb) * G::RS + slice * G::C1 + col;
 #pragma unroll
-              for (int eb = 0; eb < EB; eb++) {
-                cpx *pr = s_rows + (q * G::R2 + tf + G::T1 * eb) * G::RS + slice * G::C1 + col;
-#pragma unroll
-                for (int j = 0; j < NIT; j++)
-                  pr[j * NSLICE * G::C1] = mk(keep[NSLICE * r + q][2 * (j * EB + eb)], keep[NSLICE * r + q][2 * (j * EB + eb) + 1]);
-              }
+              for (int j = 0; j < NIT; j++)
+                pr[j * NSLICE * G::C1] = mk(keep[NSLICE * r + q][2 * (j * EB + eb)], keep[NSLICE * r + q][2 * (j * EB + eb) + 1]);
             }
           }
-          __syncthreads();
+        };
+        __syncthreads();
+        dump(std::integral_constant<int, 0>());
+        __syncthreads();
+        auto round = [&](auto rc) {
+          constexpr int r = decltype(rc)::value;
           int lo_ = l;
           asm volatile("" : "+v"(lo_));
           four_load2_rows<LOGN>(vn, s_rows, slice, lo_);
-          four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, slice + NSLICE * r, lo_, ftab2, sx);
+          if constexpr (r + 1 < RRB) {
+            four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, slice + NSLICE * r, lo_, ftab2, sx, nullptr,
+                                                     [&]() { dump(std::integral_constant<int, r + 1>()); });
+          } else {
+            four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, slice + NSLICE * r, lo_, ftab2, sx);
+          }
 #pragma unroll
           for (int e = 0; e < 16; e++) v[e] = vn[e];
-        }
+        };
+        round(std::integral_constant<int, 0>());
+        if constexpr (RRB > 1) round(std::integral_constant<int, 1>());
+        if constexpr (RRB > 2) round(std::integral_constant<int, 2>());
+        if constexpr (RRB > 3) round(std::integral_constant<int, 3>());
+        if constexpr (RRB > 4) round(std::integral_constant<int, 4>());
+        if constexpr (RRB > 5) round(std::integral_constant<int, 5>());
+        static_assert(RRB <= 6, "unrolled by hand up to 6 rounds");
         rb0 = slice + NSLICE * RRB;
       }
 #pragma unroll 1
