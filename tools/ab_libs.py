@@ -20,7 +20,7 @@ def plans(lib):
         if what == "rfft":
             e = lib.clfa_rfft_create(C.byref(h), 0, 16384, fwd)
         else:
-            e = lib.clfa_cfft_create(C.byref(h), 0, 8192 if what == "c2c8192" else 65536, fwd)
+            e = lib.clfa_cfft_create(C.byref(h), 0, int(what[3:]) if len(what) > 3 else 65536, fwd)
         assert e == 0
         out.append(h)
     return out
@@ -28,9 +28,11 @@ def plans(lib):
 if what == "rfft":
     batch, d = 8192, torch.rand((8192, 16384), device="cuda") * 2 - 1
     unit = 8192 * 16384 * 8
-elif what == "c2c8192":
-    batch, d = 32768, torch.rand((32768, 8192, 2), device="cuda") * 2 - 1
-    unit = 32768 * 8192 * 16
+elif len(what) > 3:
+    n = int(what[3:])
+    batch = (1 << 28) // n
+    d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
+    unit = batch * n * 16
 else:
     batch, d = 4096, torch.rand((4096, 65536, 2), device="cuda") * 2 - 1
     unit = 4096 * 65536 * 16
