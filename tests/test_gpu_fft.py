@@ -136,13 +136,29 @@ def test_cfft_device_resident_batch():
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_cfft_large_kernel_variants(variant):
-    n, batch = 65536, 5
+    n, batch = 65536, 70          # more than grid / 4 transforms: the persistent kernels, not the small-batch pair
     x = util.lcg_complex(31 + variant, n * batch).reshape(batch, n)
     plan = fa.Clcfft(0, n, True)
     assert plan.set_variant(variant) == 0
     y = x.copy()
     assert plan.transform(y) == 0
     assert_parity(y, oracle.cfft(x, True), what="variant %d" % variant)
+
+
+@pytest.mark.parametrize("n,batch", [(16384, 70), (16384, 300), (32768, 70), (32768, 300), (65536, 70), (65536, 300)])
+def test_cfft_persistent_kernel_ragged(n, batch):
+    """the persistent four-step kernel (intermediate in LDS + registers) with batch counts that are
+    neither small enough for the small-batch kernels nor multiples of the grid: every transform
+    against the oracle, and the round trip"""
+    x = util.lcg_complex(977 + n + batch, n * batch).reshape(batch, n)
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    y = x.copy()
+    assert f.transform(y) == 0
+    assert_parity(y, oracle.cfft(x, True), what="fwd n=%d batch=%d" % (n, batch))
+    worst = max(util.rel_err(y[b], oracle.cfft(x[b:b + 1], True)[0])[0] for b in (0, 1, batch // 2, batch - 1))
+    assert worst < 1e-6, worst
+    assert i.transform(y) == 0
+    assert_parity(y, x, what="round trip n=%d batch=%d" % (n, batch))
 
 
 # ---- a7/a8/a9: r2c / c2r -----------------------------------------------------------------
