@@ -103,7 +103,8 @@ CLFA_API const char *clfa_fft_kernel_name(const clfa_fft *plan);
 /* waits for `stream` and returns CLFA_SUCCESS, or CLFA_OUT_OF_RESOURCES if the large-N kernel's
  * bounded dependency waits ever timed out during the plan's last launch (results then invalid) */
 CLFA_API int clfa_fft_sync_check(clfa_fft *plan, void *stream);
-/* tuning: variant id of the large-N kernel (0 = default); returns CLFA_INVALID_VALUE if unknown */
+/* tuning: variant id of the n = 2^14..2^16 kernel (0 = default, 1..9 = older shapes kept for A/B);
+ * returns CLFA_INVALID_VALUE if unknown */
 CLFA_API int clfa_fft_set_variant(clfa_fft *plan, int variant);
 
 /* the reference's `reorder` kernel as a stand-alone op (cl_fft.cpp:24-27):

@@ -8,8 +8,8 @@ namespace clfa {
 
 enum FftMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2 };
 
-// Largest complex length the single-workgroup LDS kernel handles; above it
-// the four-step kernel (two phases through an on-die scratch) takes over.
+// Largest complex length the single-workgroup LDS kernel handles; above it the four-step kernel
+// (two phases, the intermediate in LDS + registers + a small global scratch) takes over.
 constexpr int kLdsMaxLog = 13;
 // complex lengths whose LDS kernel uses the two-level twiddle table [hi (n/64) | lo (64)]
 constexpr int kLdsTwoLevelLogLo = 6;
@@ -39,7 +39,7 @@ hipError_t launch_fft_4step(int logn, bool fwd, bool scale, int variant, cpx *da
                             const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
 const char *name_fft_4step(int logn, bool fwd, int variant);
 int fourstep_split(int logn, int *logn1, int *logn2, int *loglo);
-// XCD-cooperative four-step (the default large-N path): scratch = 8 XCDs x slots x n complex,
+// XCD-cooperative four-step (variant 7; selectable, slower than the default): scratch = 8 XCDs x slots x n complex,
 // ctl = a small control block zeroed on the stream before every launch
 constexpr int kVariantCoop = 7;
 size_t coop_ctl_bytes();
