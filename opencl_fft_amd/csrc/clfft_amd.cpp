@@ -116,6 +116,32 @@ struct DevBuf {
   }
 };
 
+// pinned host memory mapped into the device's address space: kernels read / write it directly over
+// PCIe.  For the few KiB of one audio block that beats three hipMemcpyAsync calls (10-15 us each).
+struct HostBuf {
+  void *h = nullptr;   // host pointer
+  void *d = nullptr;   // the same memory as the device sees it
+  size_t bytes = 0;
+  int ensure(size_t want) {
+    if (want <= bytes) return 0;
+    release();
+    hipError_t e = hipHostMalloc(&h, want, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      release();
+      return map_hip(e);
+    }
+    bytes = want;
+    return 0;
+  }
+  void release() {
+    if (h) (void)hipHostFree(h);
+    h = d = nullptr;
+    bytes = 0;
+  }
+};
+
 int upload(DevBuf &b, const void *src, size_t bytes) {
   int e = b.ensure(bytes);
   if (e) return e;
@@ -172,6 +198,7 @@ struct clfa_pconv {
   DevBuf half, w2f, w2i;             // tables (cl_conv.cpp:263-287)
   DevBuf ringA, ringB, acc, tail;    // spec1, spec2, in1-as-accumulator, olap tail
   DevBuf in1, in2, out, ir;          // staging for the host entry points
+  HostBuf zin1, zin2, zout;          // ... zero-copy staging for small blocks
   DevBuf four, scratch, work;        // partitions above the LDS sizes: large-N tables, scratch, work frames
   FftTables big;
 };
@@ -588,6 +615,9 @@ void clfa_pconv_destroy(clfa_pconv *p) {
   for (DevBuf *b : {&p->half, &p->w2f, &p->w2i, &p->ringA, &p->ringB, &p->acc, &p->tail, &p->in1, &p->in2,
                     &p->out, &p->ir, &p->four, &p->scratch, &p->work})
     b->release();
+  p->zin1.release();
+  p->zin2.release();
+  p->zout.release();
   delete p;
 }
 
@@ -678,16 +708,25 @@ int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void
                                (const cpx *)p->w2f.p, (const cpx *)p->w2i.p, s));
     return CLFA_SUCCESS;
   }
-  // forward chain(s): cl_conv.cpp:399-419 / 465-513
-  if ((e = pconv_forward(p, (const float *)in1, p->pts, (cpx *)p->ringA.p, p->wp, s))) return e;
-  if (in2 && (e = pconv_forward(p, (const float *)in2, p->pts, (cpx *)p->ringB.p, p->wp2, s))) return e;
+  const bool lds = p->g.logb <= kLdsMaxLog;
+  // forward chain(s): cl_conv.cpp:399-419 / 465-513 (both inputs of a time-varying block in one launch)
+  if (lds && in2) {
+    HIP_TRY(launch_pconv_forward(p->g, (const float *)in1, p->pts, (cpx *)p->ringA.p, p->wp, (const cpx *)p->half.p,
+                                 (const cpx *)p->w2f.p, s, (const float *)in2, (cpx *)p->ringB.p, p->wp2));
+  } else {
+    if ((e = pconv_forward(p, (const float *)in1, p->pts, (cpx *)p->ringA.p, p->wp, s))) return e;
+    if (in2 && (e = pconv_forward(p, (const float *)in2, p->pts, (cpx *)p->ringB.p, p->wp2, s))) return e;
+  }
   p->wp = p->wp != p->g.nparts - 1 ? p->wp + 1 : 0;            // cl_conv.cpp:424 / 516
   if (in2) p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;  // cl_conv.cpp:519
-  // cl_conv.cpp:428-449
+  // cl_conv.cpp:428-449.  (Adding the partial sums of a split MAC inside the single-workgroup inverse kernel
+  // instead of the wide k_pconv_reduce launch was measured: 22 -> 130 us per block for one channel.)
   HIP_TRY(launch_pconv_mac(p->g, (const cpx *)p->ringA.p, (const cpx *)p->ringB.p, p->wp, (cpx *)p->acc.p, s));
   if ((e = pconv_inverse(p, (float *)out, s))) return e;
   return CLFA_SUCCESS;
 }
+
+constexpr size_t kZeroCopyMax = 256 << 10;   // bytes per block up to which the host entry points go zero-copy
 
 static int pconv_host(clfa_pconv *p, float *out, const float *in1, const float *in2) {
   if (!p) return CLFA_INVALID_VALUE;
@@ -696,6 +735,17 @@ static int pconv_host(clfa_pconv *p, float *out, const float *in1, const float *
   HIP_TRY(hipSetDevice(p->di.device));
   const size_t blk = sizeof(float) * (size_t)p->g.channels * p->pts;
   int e;
+  if (blk <= kZeroCopyMax) {
+    // one audio block of a few channels: the kernels read the input from, and write the output to,
+    // mapped pinned host memory — no copy calls, one synchronisation (cl_conv.cpp:399, 455)
+    if ((e = p->zin1.ensure(blk)) || (e = p->zout.ensure(blk)) || (in2 && (e = p->zin2.ensure(blk)))) return e;
+    memcpy(p->zin1.h, in1, blk);
+    if (in2) memcpy(p->zin2.h, in2, blk);
+    if ((e = clfa_pconv_process_dev(p, p->zout.d, p->zin1.d, in2 ? p->zin2.d : nullptr, p->stream))) return e;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    memcpy(out, p->zout.h, blk);
+    return CLFA_SUCCESS;
+  }
   if ((e = p->in1.ensure(blk)) || (e = p->out.ensure(blk))) return e;
   HIP_TRY(hipMemcpyAsync(p->in1.p, in1, blk, hipMemcpyHostToDevice, p->stream));
   if (in2) {

@@ -22,7 +22,15 @@ template <int LOGB>
 __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_fwd(const float *__restrict__ in, long in_stride,
                                                                 cpx *__restrict__ ring, int frame, int nparts,
                                                                 int channels, const cpx *__restrict__ tab_g,
-                                                                const cpx *__restrict__ w2_g) {
+                                                                const cpx *__restrict__ w2_g,
+                                                                const float *__restrict__ in_b, cpx *__restrict__ ring_b,
+                                                                int frame_b) {
+  // blockIdx.y = 1: the second input of a time-varying block (its own ring and frame), same launch
+  if (blockIdx.y == 1) {
+    in = in_b;
+    ring = ring_b;
+    frame = frame_b;
+  }
   using G = LdsGeom<LOGB>;
   constexpr int N = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
   __shared__ cpx s_tab[G::HALF];
@@ -70,21 +78,23 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_fwd(const float *__
 
 template <int LOGB>
 static hipError_t launch_fwd_one(const PconvGeom &g, const float *in, long in_stride, cpx *ring, int frame,
-                                 const cpx *half, const cpx *w2f, hipStream_t s) {
+                                 const cpx *half, const cpx *w2f, hipStream_t s, const float *in_b, cpx *ring_b,
+                                 int frame_b) {
   using G = LdsGeom<LOGB>;
   int groups = (g.channels + G::FPW - 1) / G::FPW;
   int grid = groups < 4096 ? groups : 4096;
-  hipLaunchKernelGGL((k_pconv_fwd<LOGB>), dim3(grid), dim3(G::WG), 0, s, in, in_stride, ring, frame, g.nparts,
-                     g.channels, half, w2f);
+  hipLaunchKernelGGL((k_pconv_fwd<LOGB>), dim3(grid, in_b ? 2 : 1), dim3(G::WG), 0, s, in, in_stride, ring, frame,
+                     g.nparts, g.channels, half, w2f, in_b, ring_b, frame_b);
   return hipGetLastError();
 }
 
 hipError_t launch_pconv_forward(const PconvGeom &g, const float *in, long in_stride, cpx *ring, int frame,
-                                const cpx *half, const cpx *w2f, hipStream_t s) {
+                                const cpx *half, const cpx *w2f, hipStream_t s, const float *in_b, cpx *ring_b,
+                                int frame_b) {
   switch (g.logb) {
 #define CLFA_B(L) \
   case L:         \
-    return launch_fwd_one<L>(g, in, in_stride, ring, frame, half, w2f, s);
+    return launch_fwd_one<L>(g, in, in_stride, ring, frame, half, w2f, s, in_b, ring_b, frame_b);
     CLFA_B(1) CLFA_B(2) CLFA_B(3) CLFA_B(4) CLFA_B(5) CLFA_B(6) CLFA_B(7) CLFA_B(8) CLFA_B(9) CLFA_B(10)
     CLFA_B(11) CLFA_B(12) CLFA_B(13)
 #undef CLFA_B
@@ -188,7 +198,7 @@ int pconv_mac_split(const PconvGeom &g) {
 }
 
 hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp, cpx *acc,
-                            hipStream_t s) {
+                            hipStream_t s, bool reduce) {
   long total = (long)g.channels * (g.bins / 2);
   long grid = (total + 255) / 256;
   if (grid > 256 * 64) grid = 256 * 64;
@@ -197,7 +207,7 @@ hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *rin
   hipLaunchKernelGGL((k_pconv_mac<4>), dim3((int)grid, nsplit), dim3(256), 0, s, ringA, ringB, acc, wp, g.bins,
                      g.nparts, total, chunk);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || nsplit == 1) return e;
+  if (e != hipSuccess || nsplit == 1 || !reduce) return e;
   long total2 = total * 2, rgrid = (total2 + 255) / 256;
   if (rgrid > 4096) rgrid = 4096;
   hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid), dim3(256), 0, s, acc, total2, nsplit);
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_inv(const cpx *__re
                                                                 float *__restrict__ tail,
                                                                 float *__restrict__ out, int channels,
                                                                 const cpx *__restrict__ tab_g,
-                                                                const cpx *__restrict__ w2_g) {
+                                                                const cpx *__restrict__ w2_g, int nsplit) {
   using G = LdsGeom<LOGB>;
   constexpr int N = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
   __shared__ cpx s_tab[G::HALF];
@@ -224,20 +234,27 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_inv(const cpx *__re
   __syncthreads();
   cpx *xb = s_x + f * G::PADN;
   const int groups = (channels + FPW - 1) / FPW;
+  const long part = (long)channels * N;   // one partial accumulator (MAC split over the partition axis)
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int ch = g * FPW + f;
     const bool active = ch < channels;
-    const cpx *x = acc + (long)(active ? ch : 0) * N;
+    const cpx *x0 = acc + (long)(active ? ch : 0) * N;
+    // sum of the partial accumulators, ascending (the order k_pconv_reduce uses): no separate launch
+    auto x = [&](int i) {
+      cpx sum = x0[i];
+      for (int k = 1; k < nsplit; k++) sum = cadd(sum, x0[k * part + i]);
+      return sum;
+    };
     __syncthreads();
     if (active) {
       for (int i = t; i < N / 2; i += T) {
         if (i == 0) {
-          cpx c0 = x[0];
+          cpx c0 = x(0);
           xb[0] = mk(c0.x + c0.y, c0.x - c0.y);
-          xb[lds_pad(N / 2)] = x[N / 2];
+          xb[lds_pad(N / 2)] = x(N / 2);
         } else {
           cpx oi, oj;
-          c2r_pair(x[i], x[N - i], w2_g[i], oi, oj);
+          c2r_pair(x(i), x(N - i), w2_g[i], oi, oj);
           xb[lds_pad(i)] = oi;
           xb[lds_pad(N - i)] = oj;
         }
@@ -268,20 +285,20 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_inv(const cpx *__re
 
 template <int LOGB>
 static hipError_t launch_inv_one(const PconvGeom &g, const cpx *acc, float *tail, float *out, const cpx *half,
-                                 const cpx *w2i, hipStream_t s) {
+                                 const cpx *w2i, hipStream_t s, int nsplit) {
   using G = LdsGeom<LOGB>;
   int groups = (g.channels + G::FPW - 1) / G::FPW;
   int grid = groups < 4096 ? groups : 4096;
-  hipLaunchKernelGGL((k_pconv_inv<LOGB>), dim3(grid), dim3(G::WG), 0, s, acc, tail, out, g.channels, half, w2i);
+  hipLaunchKernelGGL((k_pconv_inv<LOGB>), dim3(grid), dim3(G::WG), 0, s, acc, tail, out, g.channels, half, w2i, nsplit);
   return hipGetLastError();
 }
 
 hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail, float *out, const cpx *half,
-                                const cpx *w2i, hipStream_t s) {
+                                const cpx *w2i, hipStream_t s, int nsplit) {
   switch (g.logb) {
 #define CLFA_B(L) \
   case L:         \
-    return launch_inv_one<L>(g, acc, tail, out, half, w2i, s);
+    return launch_inv_one<L>(g, acc, tail, out, half, w2i, s, nsplit);
     CLFA_B(1) CLFA_B(2) CLFA_B(3) CLFA_B(4) CLFA_B(5) CLFA_B(6) CLFA_B(7) CLFA_B(8) CLFA_B(9) CLFA_B(10)
     CLFA_B(11) CLFA_B(12) CLFA_B(13)
 #undef CLFA_B

@@ -83,16 +83,19 @@ struct PconvGeom {
 // input block (channels x pts floats) -> zero-padded 2*pts real FFT -> packed
 // spectrum frame `frame` of ring (channels x nparts x bins complex).  Unscaled,
 // reference pack (cl_conv_kernels.h:46-85).
+// in_b / ring_b / frame_b: optional second input of a time-varying block, transformed by the same launch
 hipError_t launch_pconv_forward(const PconvGeom &g, const float *in, long in_stride, cpx *ring, int frame,
-                                const cpx *half, const cpx *w2f, hipStream_t s);
+                                const cpx *half, const cpx *w2f, hipStream_t s, const float *in_b = nullptr,
+                                cpx *ring_b = nullptr, int frame_b = 0);
 // acc = sum_p A[(wp+p)%nparts] (.) B[p]  (cl_conv_kernels.h:102-118), acc: channels x bins complex
 int pconv_mac_split(const PconvGeom &g);   // partial accumulators the MAC writes (acc must hold that many)
+// reduce = false leaves the pconv_mac_split() partial sums for launch_pconv_inverse(nsplit) to add up
 hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *ringB, int wp, cpx *acc,
-                            hipStream_t s);
+                            hipStream_t s, bool reduce = true);
 // acc -> c2r -> inverse FFT -> overlap-add (cl_conv_kernels.h:87-100,120-124); out channels x pts,
 // tail channels x pts (unscaled second half kept for the next block)
 hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail, float *out,
-                                const cpx *half, const cpx *w2i, hipStream_t s);
+                                const cpx *half, const cpx *w2i, hipStream_t s, int nsplit = 1);
 // one launch per block (forward + MAC + inverse in one workgroup per channel); used when
 // pconv_fused_ok(): bins 512..4096 and enough channels to fill the chip
 bool pconv_fused_ok(const PconvGeom &g, const DeviceInfo &di);
