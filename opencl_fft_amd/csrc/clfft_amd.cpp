@@ -182,6 +182,7 @@ struct clfa_fft {
   char log[2048];
   hipStream_t stream = nullptr;
   DevBuf half, w2, four, scratch, stage, ctl;
+  HostBuf zstage;        // zero-copy staging of small host transforms
   FftTables tabs;
   // n > 65536 (extension): n = N1 x N2; `tabs` then belongs to the N2-point row transform
   BigGeom big{};
@@ -410,6 +411,7 @@ void clfa_fft_destroy(clfa_fft *p) {
   p->scratch.release();
   p->stage.release();
   p->ctl.release();
+  p->zstage.release();
   p->bigtabs.release();
   p->scratch2.release();
   delete p;
@@ -489,6 +491,11 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   return CLFA_SUCCESS;
 }
 
+// bytes per call up to which the host entry points go zero-copy: the kernels read the input from,
+// and write the result to, mapped pinned host memory (one pass each way), instead of two
+// hipMemcpyAsync calls of 10-15 us each around a kernel of a few microseconds
+constexpr size_t kZeroCopyMax = 256 << 10;
+
 // host staging in chunks of at most ~256 MiB so huge host batches do not need a
 // device buffer of their full size
 static long chunk_batches(size_t bytes_per_batch, long batch) {
@@ -504,6 +511,15 @@ int clfa_cfft_transform(clfa_fft *p, float *c, long batch) {
   if (!c || batch < 0 || p->real) return CLFA_INVALID_VALUE;
   HIP_TRY(hipSetDevice(p->di.device));
   const size_t per = sizeof(cpx) * (size_t)p->n;
+  if (batch > 0 && per * (size_t)batch <= kZeroCopyMax) {
+    int e = p->zstage.ensure(per * batch);
+    if (e) return e;
+    memcpy(p->zstage.h, c, per * batch);
+    if ((e = clfa_fft_exec_dev(p, p->zstage.d, batch, p->stream))) return e;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    memcpy(c, p->zstage.h, per * batch);
+    return CLFA_SUCCESS;
+  }
   const long cb = chunk_batches(per, batch);
   for (long b0 = 0; b0 < batch; b0 += cb) {
     long nb = batch - b0 < cb ? batch - b0 : cb;
@@ -524,6 +540,15 @@ int clfa_rfft_transform(clfa_fft *p, float *c, float *r, long batch) {
   if (!c || !r || batch < 0 || !p->real) return CLFA_INVALID_VALUE;
   HIP_TRY(hipSetDevice(p->di.device));
   const size_t per = sizeof(cpx) * (size_t)p->n;  // size floats == M complex
+  if (batch > 0 && per * (size_t)batch <= kZeroCopyMax) {
+    int e = p->zstage.ensure(per * batch);
+    if (e) return e;
+    memcpy(p->zstage.h, p->fwd ? (void *)r : (void *)c, per * batch);
+    if ((e = clfa_fft_exec_dev(p, p->zstage.d, batch, p->stream))) return e;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    memcpy(p->fwd ? (void *)c : (void *)r, p->zstage.h, per * batch);
+    return CLFA_SUCCESS;
+  }
   const long cb = chunk_batches(per, batch);
   // forward reads r and writes c; inverse reads c and writes r (cl_fft.cpp:272-294)
   char *src = (char *)(p->fwd ? (void *)r : (void *)c);
@@ -725,8 +750,6 @@ int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void
   if ((e = pconv_inverse(p, (float *)out, s))) return e;
   return CLFA_SUCCESS;
 }
-
-constexpr size_t kZeroCopyMax = 256 << 10;   // bytes per block up to which the host entry points go zero-copy
 
 static int pconv_host(clfa_pconv *p, float *out, const float *in1, const float *in2) {
   if (!p) return CLFA_INVALID_VALUE;
