@@ -2,7 +2,7 @@
 """bench.py — headline benchmark of BASELINE.json: batched 1-D c2c FFT, N=65536,
 float32, 4096 batches per GPU, device-resident, in place.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20      (the defaults)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2c", choices=["c2c", "rfft", "pconv"])
     ap.add_argument("--variant", type=int, default=-1, help="large-N kernel variant (tuning)")
     ap.add_argument("--batch", type=int, default=0, help="override batches / channels per GPU")
