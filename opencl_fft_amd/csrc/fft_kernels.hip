@@ -538,6 +538,10 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
   cpx *mid = scratch + (long)blockIdx.x * G::N;
   __syncthreads();
 
+  // prefetching form: the first column block of a transform is loaded behind the last row block of the
+  // previous one (`vnext`), so that only the very first load of the workgroup is exposed
+  cpx vnext[16];
+  if constexpr (PF) four_load1<LOGN, NT ? 1 : 0>(vnext, data + (long)blockIdx.x * G::N, slice, l);
 #pragma unroll 1
   for (long b = blockIdx.x; b < batch; b += gridDim.x) {
     cpx *x = data + b * (long)G::N;
@@ -564,11 +568,13 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       cpx v[16], vn[16];
       vkeep keep[NE > 0 ? NE : 1];
       int it = 0;   // the slice's column-block counter: uniform, indexes `keep`
-      four_load1<LOGN, NT ? 1 : 0>(v, x, slice, l);
       // consumed before the loop: otherwise the wait for these loads is merged into the loop header,
       // where it turns into vmcnt(0) on the back edge too and drains every iteration's scratch stores
 #pragma unroll
-      for (int e = 0; e < 16; e++) asm volatile("" : "+v"(v[e]));
+      for (int e = 0; e < 16; e++) {
+        asm volatile("" : "+v"(vnext[e]));
+        v[e] = vnext[e];
+      }
 #pragma unroll 1
       for (int cb = slice; cb + NSLICE < G::NCB; cb += NSLICE) {
         int lo_ = l;   // opaque per iteration (see above)
@@ -655,6 +661,10 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
       {
         int lo_ = l;
         asm volatile("" : "+v"(lo_));
+        // the next transform's first column block (index clamped to the last transform: straight-line loads)
+        long bn = b + gridDim.x;
+        bn = bn < batch ? bn : batch - 1;
+        four_load1<LOGN, NT ? 1 : 0>(vnext, data + bn * (long)G::N, slice, lo_);
         four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, G::NRB - NSLICE + slice, lo_, ftab2, sx);
       }
       __syncthreads();
