@@ -239,31 +239,9 @@ constexpr int pass_last_logns(int LOGN, int LOGE) { return LOGN - pass_rem_logr(
 CLFA_HD int lds_pad(int p) { return p + (p >> 4); }
 constexpr int lds_padded_size(int n) { return n + (n >> 4) + 1; }
 
-// Half-table twiddle lookup: tab holds W_n^k for k in [0, n/2) (forward sign);
-// W_n^(k+n/2) = -W_n^k; inverse = conjugate.
-template <int LOGN, bool FWD, class Tab> CLFA_HD cpx tw_lookup(const Tab &tab, int k) {
-  if constexpr (LOGN == 0) return mk(1.f, 0.f);
-  constexpr int half = (1 << LOGN) >> 1;
-  cpx w = tab[k & (half - 1)];
-  if (k & half) w = mk(-w.x, -w.y);
-  if (!FWD) w.y = -w.y;
-  return w;
-}
-
-// Two-level twiddle table: W_n^k = hi[k >> LOGLO] * lo[k & (2^LOGLO - 1)], hi[j] = W_n^(j * 2^LOGLO),
-// lo[j] = W_n^j, both rounded from double.  n/2^LOGLO + 2^LOGLO entries instead of n/2: it lets
-// the 8192-point kernel keep two workgroups per CU.  One extra complex multiply per lookup.
-template <int LOGLO> struct TwoLevelTab {
-  const cpx *hi;
-  const cpx *lo;
-};
-template <int LOGN, bool FWD, int LOGLO> CLFA_HD cpx tw_lookup(const TwoLevelTab<LOGLO> &tab, int k) {
-  cpx w = cmul(tab.hi[k >> LOGLO], tab.lo[k & ((1 << LOGLO) - 1)]);
-  if (!FWD) w.y = -w.y;
-  return w;
-}
-// v * W_n^k for a forward transform, v * conj(W_n^k) for an inverse one (the conjugation rides on
-// the multiply's operand modifiers)
+// Twiddle multiplies: v * W_n^k for a forward transform, v * conj(W_n^k) for an inverse one (the
+// conjugation rides on the multiply's operand modifiers).
+// Half table: tab holds W_n^k for k in [0, n/2) (forward sign); W_n^(k+n/2) = -W_n^k.
 template <int LOGN, bool FWD, class Tab> CLFA_HD cpx cmul_tw(cpx v, const Tab &tab, int k) {
   if constexpr (LOGN == 0) return v;
   constexpr int half = (1 << LOGN) >> 1;
@@ -271,6 +249,13 @@ template <int LOGN, bool FWD, class Tab> CLFA_HD cpx cmul_tw(cpx v, const Tab &t
   if (k & half) r = mk(-r.x, -r.y);
   return r;
 }
+// Two-level twiddle table: W_n^k = hi[k >> LOGLO] * lo[k & (2^LOGLO - 1)], hi[j] = W_n^(j * 2^LOGLO),
+// lo[j] = W_n^j, both rounded from double.  n/2^LOGLO + 2^LOGLO entries instead of n/2: it lets
+// the 8192-point kernel keep two workgroups per CU.  One extra complex multiply per lookup.
+template <int LOGLO> struct TwoLevelTab {
+  const cpx *hi;
+  const cpx *lo;
+};
 // full table W_n^k, k < n (forward sign): no half-table sign logic (3-4 VALU per lookup); used where LDS allows
 struct FullTab {
   const cpx *p;
