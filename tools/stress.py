@@ -1,0 +1,21 @@
+"""dev tool: long round-trip stress of the persistent four-step kernels (intermediate handed over through
+LDS + registers): any race in the hand-over would show up as a sporadic round-trip error."""
+import sys
+sys.path.insert(0, ".")
+import torch
+import opencl_fft_amd as fa
+
+for n, batch, iters in [(65536, 4096, 300), (65536, 777, 300), (32768, 8192, 200), (16384, 16384, 200), (16384, 333, 300)]:
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    x = torch.rand((batch, n, 2), device="cuda") * 2 - 1
+    d = x.clone()
+    worst = 0.0
+    for k in range(iters):
+        assert f.exec_device(d, batch) == 0 and i.exec_device(d, batch) == 0
+        if k % 10 == 9:
+            err = float((d - x).norm() / x.norm())
+            worst = max(worst, err)
+            assert err < 2e-5, (n, batch, k, err)   # error grows slowly with the number of round trips
+            d.copy_(x)
+    print("n=%d batch=%d: %d round trips, worst relL2 after 10 round trips %.2e" % (n, batch, iters, worst), flush=True)
+print("OK")
