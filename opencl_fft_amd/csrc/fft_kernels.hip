@@ -3,11 +3,14 @@
 // Replaces the reference's launch chain reorder + log2(N) x fft (+ conv/iconv)
 // (cl_fft.cpp:24-41, 138-151, 178-205) by
 //   k_fft_lds    one HBM pass: a transform (n <= 8192) lives in VGPRs + LDS of one
-//                workgroup; r2c pack / c2r unpack fused as LDS epilogue / prologue;
-//   k_fft_4step  n = 2^14..2^16: N1 x N2 decomposition, both phases in ONE
-//                persistent kernel; the intermediate goes through a per-workgroup
-//                scratch slot that is small enough (grid x 512 KiB) to live in the
-//                256 MiB Infinity Cache, so HBM sees one read + one write per sample;
+//                workgroup; r2c pack / c2r unpack fused (the two bins of a pair meet in
+//                one lane's registers where the pass structure allows);
+//   k_fft_4step  n = 2^14..2^16: N1 x N2 decomposition, both phases in ONE persistent
+//                kernel, one 512-lane workgroup per CU; the intermediate stays on the CU —
+//                two row blocks in LDS, up to ten in the registers of the lanes that
+//                computed them, handed over through LDS — all of it for n <= 2^15, 3/4 at
+//                n = 2^16 (the rest goes through a 512 KiB scratch slot per workgroup);
+//   k_big_cols / k_big_transpose  n = 2^17..2^24, composed with the two above;
 //   k_r2c_pack / k_c2r_unpack, k_reorder  stand-alone forms of the reference's
 //                conv / iconv / reorder kernels.
 #include <cstdlib>
