@@ -249,6 +249,133 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   }
 }
 
+// ---------------------------------------------------------------------------------
+// n = 8 .. 64 (packed real: .. 256): the same passes, but global memory is touched in workgroup-wide coalesced rows
+// ---------------------------------------------------------------------------------
+// With T = n/16 < 8 lanes per transform, "lane t owns positions t + T*e" makes a wave's load touch 64
+// different cache lines with 8..32 useful bytes each (measured: n = 16 at 0.96 TB/s).  Here the 256
+// transforms of a workgroup (one contiguous chunk of 256*E elements) are read in E fully coalesced
+// rows of 256 elements, parked in the per-transform padded LDS buffers at their natural positions, and
+// picked up from there in the owning lanes' order (pass_gather_padded); results go back the same way.
+template <int LOGN, bool FWD, int MODE, bool SCALE>
+__global__ __launch_bounds__(256) void k_fft_small(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
+                                                   const cpx *__restrict__ w2_g, long batch) {
+  using G = LdsGeom<LOGN>;
+  constexpr int N = G::N, E = G::E, T = G::T, FPW = G::FPW, CHUNK = FPW * N;
+  static_assert(G::WG == 256 && CHUNK == 256 * E, "one chunk = E rows of 256 elements");
+  __shared__ cpx s_tab[G::HALF];
+  __shared__ cpx s_w2[MODE == MODE_C2C ? 1 : N / 2];
+  __shared__ cpx s_x[FPW * G::PADN];
+  const int tid = threadIdx.x;
+  const int f = tid / T, t = tid % T;
+  for (int i = tid; i < N / 2; i += 256) s_tab[i] = tab_g[i];
+  if constexpr (MODE != MODE_C2C)
+    for (int i = tid; i < N / 2; i += 256) s_w2[i] = w2_g[i];
+  cpx *xb = s_x + f * G::PADN;
+  // element `tid + 256*e` of the chunk: transform (tid >> LOGN) + (256 >> LOGN)*e, position tid & (N-1)
+  cpx *park = s_x + (tid >> LOGN) * G::PADN + lds_pad(tid & (N - 1));
+  constexpr int PARK_STEP = (256 >> LOGN) * G::PADN;
+  const long groups = (batch + FPW - 1) / FPW;
+  const long total = batch * (long)N;
+  long g = blockIdx.x;
+  if (g >= groups) return;
+  cpx raw[E];
+  auto load_rows = [&](long grp) {
+    const long base = grp * CHUNK;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      long idx = base + tid + 256 * e;
+      idx = idx < total ? idx : total - 1;   // ragged last group: clamped, straight-line
+      raw[e] = ld_nt(data + idx);
+    }
+  };
+  // the reference's pair maps (cl_fft.cpp:178-205) in place on the natural-order LDS copy: lane t of a
+  // transform owns pairs i = t + T*k (and their partners n - i); pair 0 is the packed DC/Nyquist bin
+  auto pair_map = [&]() {
+#pragma unroll
+    for (int k = 0; k < E / 2; k++) {
+      const int i = t + T * k, j = i == 0 ? N / 2 : N - i;
+      const cpx ci = xb[lds_pad(i)], cj = xb[lds_pad(j)];
+      cpx oi, oj;
+      if constexpr (MODE == MODE_R2C) r2c_pair(ci, cj, s_w2[i], oi, oj);
+      else c2r_pair(ci, cj, s_w2[i], oi, oj);
+      if (k == 0) {   // selects, not a branch
+        const bool z = i == 0;
+        const float h = MODE == MODE_R2C ? .5f : 1.f;
+        oi = mk(z ? (ci.x + ci.y) * h : oi.x, z ? (ci.x - ci.y) * h : oi.y);
+        oj = mk(z ? cj.x : oj.x, z ? cj.y : oj.y);
+      }
+      xb[lds_pad(i)] = oi;
+      xb[lds_pad(j)] = oj;
+    }
+  };
+  load_rows(g);
+#pragma unroll
+  for (int e = 0; e < E; e++) asm volatile("" : "+v"(raw[e]));
+  __syncthreads();
+#pragma unroll 1
+  for (; g < groups; g += gridDim.x) {
+    cpx v[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) park[e * PARK_STEP] = raw[e];
+    {  // the next chunk's rows fly behind this one's passes
+      long gn = g + gridDim.x;
+      load_rows(gn < groups ? gn : groups - 1);
+    }
+    __syncthreads();
+    if constexpr (MODE == MODE_C2R) {
+      pair_map();
+      __syncthreads();
+    }
+    pass_gather_padded<LOGN, G::LOGE>(v, t, xb);
+    wg_passes<LOGN, G::LOGE, 0, FWD>(v, t, s_tab, xb);
+    if constexpr (SCALE) {
+#pragma unroll
+      for (int e = 0; e < E; e++) v[e] = cscale(v[e], 1.0f / (float)N);
+    }
+    __syncthreads();   // every lane is done with the exchange buffer
+    dif_scatter_padded<LOGN, G::LOGE>(v, t, xb);
+    __syncthreads();
+    if constexpr (MODE == MODE_R2C) {
+      pair_map();
+      __syncthreads();
+    }
+    const long base = g * CHUNK;
+    const bool full = base + CHUNK <= total;   // uniform
+    if (full) {
+#pragma unroll
+      for (int e = 0; e < E; e++) st_nt(data + base + tid + 256 * e, park[e * PARK_STEP]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; e++)
+        if (base + tid + 256 * e < total) data[base + tid + 256 * e] = park[e * PARK_STEP];
+    }
+    __syncthreads();   // the parked results are out before the next chunk is parked
+#pragma unroll
+    for (int e = 0; e < E; e++) asm volatile("" : "+v"(raw[e]));
+  }
+}
+
+template <int LOGN, bool FWD, int MODE, bool SCALE>
+static hipError_t launch_small_one(cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
+  using G = LdsGeom<LOGN>;
+  long groups = (batch + G::FPW - 1) / G::FPW;
+  static int occ = 0;
+  if (occ == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fft_small<LOGN, FWD, MODE, SCALE>, 256, 0) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = 1;
+    }
+    occ = nb;
+  }
+  long cap = (long)di.num_cus * occ;
+  int grid = (int)(groups < cap ? groups : cap);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_fft_small<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(256), 0, s, data, t.half, t.w2, batch);
+  return hipGetLastError();
+}
+
 template <int LOGN, bool FWD, int MODE, bool SCALE>
 static hipError_t launch_lds_one(cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
                                  hipStream_t s) {
@@ -277,8 +404,14 @@ static hipError_t launch_lds_one(cpx *data, const FftTables &t, long batch, cons
 template <int LOGN>
 static hipError_t launch_lds_n(bool fwd, int mode, bool scale, cpx *data, const FftTables &t, long batch,
                                const DeviceInfo &di, hipStream_t s) {
-#define CLFA_CASE(F, M, S) \
-  if (fwd == F && mode == M && scale == S) return launch_lds_one<LOGN, F, M, S>(data, t, batch, di, s);
+#define CLFA_CASE(F, M, S)                                                                                     \
+  if (fwd == F && mode == M && scale == S) {                                                                   \
+    /* sub-64-byte rows per transform (and the packed real transforms up to 256 bins, whose pair maps  */     \
+    /* store 8-byte pieces): coalesced staging through LDS                                              */     \
+    if constexpr (LOGN >= 2 && (LOGN <= 6 || (M != MODE_C2C && LOGN <= 8)))                                     \
+      return launch_small_one<LOGN, F, M, S>(data, t, batch, di, s);                                           \
+    else return launch_lds_one<LOGN, F, M, S>(data, t, batch, di, s);                                          \
+  }
   CLFA_CASE(true, MODE_C2C, true)
   CLFA_CASE(true, MODE_C2C, false)
   CLFA_CASE(false, MODE_C2C, false)
