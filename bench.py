@@ -90,6 +90,9 @@ def main():
     # rehearsal hooks (tests only): CLFA_BENCH_BACKEND=gloo CLFA_BENCH_DEVICE=0 run several ranks on ONE GPU
     backend = os.environ.get("CLFA_BENCH_BACKEND", "nccl")
     local = int(os.environ.get("CLFA_BENCH_DEVICE", local))
+    ndev = torch.cuda.device_count()
+    if ndev > 0:
+        local %= ndev      # a launcher that narrows each rank to one visible device leaves only ordinal 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
