@@ -74,7 +74,7 @@ CLFA_API int clfa_r2c_twiddle_table(int m, int forward, float *out);
 /* ---- complex FFT: cl_fft::Clcfft ------------------------------------------- */
 /* Clcfft::Clcfft(device_id, size, fwd), cl_fft.cpp:44-125.  n = 2^k, 2..65536 is the reference's
  * range (its stage kernel overflows int32 above that, cl_fft.cpp:32); as an extension n up to 2^24
- * is accepted (columns + rows + transpose, 256 MiB of workspace).
+ * is accepted (two passes up to 2^20, three above; 256 MiB of workspace).
  * On failure *plan is still a valid handle whose clfa_fft_get_error() reports
  * the setup error (the reference's constructors never throw, cl_fft.h:65). */
 CLFA_API int clfa_cfft_create(clfa_fft **plan, int device, int n, int forward);

@@ -1411,7 +1411,7 @@ hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s) {
 // n = 2^17 .. 2^24: beyond the reference's reach (its stage kernel overflows int32 above 65536,
 // cl_fft.cpp:32) — an extension, composed from the kernels above
 // ---------------------------------------------------------------------------------
-// n = N1 x N2, N1 = 32..256 (columns), N2 = 4096..65536 (rows):
+// Above 2^20 (two passes below it, see k_big2_*): n = N1 x N2, N1 = 32..256 (columns), N2 = 8192..65536 (rows):
 //   1. k_big_cols: N1-point FFT down 16..128 adjacent columns of data[n1][n2], times W_n^(n2 k1),
 //      to scratch[k1][n2]                                                       (16 B/sample)
 //   2. the batched row kernel of this file over the n-contiguous rows of scratch, N1 * batch of them,
@@ -1424,8 +1424,13 @@ hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s) {
 int big_split(int logn, BigGeom *g) {
   if (logn <= kMaxLog || logn > kBigMaxLog) return -1;
   g->logn = logn;
-  g->logn2 = logn <= 20 ? 12 : (logn == 21 ? 13 : logn - 8);
-  g->logn1 = logn - g->logn2;
+  if (logn <= 20) {   // two passes, N1 x N2 with both <= 1024 (k_big2_cols / k_big2_rows)
+    g->logn1 = logn / 2;
+    g->logn2 = logn - g->logn1;
+  } else {            // three passes
+    g->logn2 = logn == 21 ? 13 : logn - 8;
+    g->logn1 = logn - g->logn2;
+  }
   g->loglo = 12;
   return 0;
 }
@@ -1503,11 +1508,138 @@ static hipError_t launch_big_n1(const BigGeom &g, bool fwd, bool scale, cpx *dat
   return hipGetLastError();
 }
 
+// ---- n = 2^17 .. 2^20 in TWO passes (32 B/sample): both factors <= 1024, so a block of 16 columns
+// (pass 1) or 16 rows (pass 2) of one transform fits the LDS of a CU (128-139 KiB, one workgroup of
+// N1 resp. N2 lanes per CU) and both passes move 128-byte segments:
+//   k_big2_cols: data[n1][16 columns] -> N1-point FFTs, times W_n^(n2 k1) -> scratch[k1][n2]
+//   k_big2_rows: scratch[16 rows k1][n2] -> N2-point FFTs -> data[k2 * N1 + k1] (natural order)
+template <int LOGN1, int LOGNS, bool FWD>
+__device__ __forceinline__ void col_passes(cpx (&v)[16], int tf, const cpx *tab, cpx *sx, int col) {
+  pass_compute<LOGN1, 4, LOGNS, FWD>(v, tf, tab);
+  constexpr int LOGR = pass_logr(LOGN1, 4, LOGNS);
+  if constexpr (LOGNS + LOGR < LOGN1) {
+    __syncthreads();
+    pass_scatter<LOGN1, 4, LOGNS>(v, tf, [&](int p, cpx val) { sx[p * 16 + col] = val; });
+    __syncthreads();
+    pass_gather<LOGN1, 4>(v, tf, [&](int p) { return sx[p * 16 + col]; });
+    col_passes<LOGN1, LOGNS + LOGR, FWD>(v, tf, tab, sx, col);
+  }
+}
+template <int LOGN1, bool FWD>
+__global__ __launch_bounds__(1 << LOGN1) void k_big2_cols(const cpx *__restrict__ data, cpx *__restrict__ scratch,
+                                                          const cpx *__restrict__ tabs_g, int logn2, int loglo) {
+  constexpr int N1 = 1 << LOGN1, T1 = N1 / 16;
+  __shared__ cpx s_tab1[N1 / 2];
+  __shared__ cpx s_x[N1 * 16];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N1 / 2; i += N1) s_tab1[i] = tabs_g[i];
+  const cpx *tlo = tabs_g + N1 / 2, *thi = tlo + (1 << loglo);
+  const int col = tid % 16, tf = tid / 16;
+  const int n2 = blockIdx.x * 16 + col;
+  const long base = ((long)blockIdx.y << (LOGN1 + logn2)) + n2;
+  cpx v[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = ld_nt(data + base + ((long)(tf + T1 * e) << logn2));
+  __syncthreads();
+  col_passes<LOGN1, 0, FWD>(v, tf, s_tab1, s_x, col);
+  const int mlo = (1 << loglo) - 1;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int k1 = tf + T1 * e;
+    const int ex = n2 * k1;  // < n <= 2^20
+    scratch[base + ((long)k1 << logn2)] = cmulc<!FWD>(v[e], cmul(tlo[ex & mlo], thi[ex >> loglo]));
+  }
+}
+
+// all passes but the last with the lanes of a row adjacent (tf fast); the last one with the 16 rows on
+// the fast lane index, so that the transposed store is 128-byte segments
+template <int LOGN2, int LOGNS, bool FWD>
+__device__ __forceinline__ void row_passes(cpx (&v)[16], int l, const cpx *tab, cpx *sx) {
+  constexpr int T2 = (1 << LOGN2) / 16, S2 = lds_padded_size(1 << LOGN2) | 1;
+  constexpr int LOGR = pass_logr(LOGN2, 4, LOGNS), NEXT = LOGNS + LOGR;
+  const int tf = l % T2, row = l / T2;
+  pass_compute<LOGN2, 4, LOGNS, FWD>(v, tf, tab);
+  __syncthreads();
+  pass_scatter_padded<LOGN2, 4, LOGNS>(v, tf, sx + row * S2);
+  __syncthreads();
+  if constexpr (NEXT + pass_logr(LOGN2, 4, NEXT) < LOGN2) {
+    pass_gather_padded<LOGN2, 4>(v, tf, sx + row * S2);
+    row_passes<LOGN2, NEXT, FWD>(v, l, tab, sx);
+  } else {
+    const int row2 = l % 16, tf2 = l / 16;
+    pass_gather_padded<LOGN2, 4>(v, tf2, sx + row2 * S2);
+    pass_compute<LOGN2, 4, NEXT, FWD>(v, tf2, tab);
+  }
+}
+template <int LOGN2, bool FWD, bool SCALE>
+__global__ __launch_bounds__(1 << LOGN2) void k_big2_rows(const cpx *__restrict__ scratch, cpx *__restrict__ data,
+                                                          const cpx *__restrict__ tab_g, int logn1, float inv_n) {
+  constexpr int N2 = 1 << LOGN2, T2 = N2 / 16, S2 = lds_padded_size(N2) | 1;
+  __shared__ cpx s_tab2[N2 / 2];
+  __shared__ cpx s_x[16 * S2];
+  const int l = threadIdx.x;
+  for (int i = l; i < N2 / 2; i += N2) s_tab2[i] = tab_g[i];
+  const long tbase = (long)blockIdx.y << (LOGN2 + logn1);
+  cpx v[16];
+  {
+    const int tf = l % T2, row = l / T2;
+    const cpx *p = scratch + tbase + ((long)(blockIdx.x * 16 + row) << LOGN2) + tf;
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = p[T2 * e];
+  }
+  __syncthreads();
+  row_passes<LOGN2, 0, FWD>(v, l, s_tab2, s_x);
+  const int row2 = l % 16, tf2 = l / 16;
+  cpx *dst = data + tbase + blockIdx.x * 16 + row2;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    cpx o = v[e];
+    if constexpr (SCALE) o = cscale(o, inv_n);
+    st_nt(dst + ((long)(tf2 + T2 * e) << logn1), o);
+  }
+}
+
+template <int LOGN1>
+static hipError_t launch_big2_cols(const BigGeom &g, bool fwd, const cpx *data, cpx *scratch, const cpx *bigtabs,
+                                   long batch, hipStream_t s) {
+  const dim3 grid((1 << g.logn2) / 16, (unsigned)batch);
+  if (fwd) hipLaunchKernelGGL((k_big2_cols<LOGN1, true>), grid, dim3(1 << LOGN1), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  else hipLaunchKernelGGL((k_big2_cols<LOGN1, false>), grid, dim3(1 << LOGN1), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  return hipGetLastError();
+}
+template <int LOGN2>
+static hipError_t launch_big2_rows(const BigGeom &g, bool fwd, bool scale, const cpx *scratch, cpx *data,
+                                   const cpx *half2, long batch, hipStream_t s) {
+  const dim3 grid((1 << g.logn1) / 16, (unsigned)batch);
+  const float inv_n = 1.0f / (float)(1L << g.logn);
+  if (fwd && scale) hipLaunchKernelGGL((k_big2_rows<LOGN2, true, true>), grid, dim3(1 << LOGN2), 0, s, scratch, data, half2, g.logn1, inv_n);
+  else if (fwd) hipLaunchKernelGGL((k_big2_rows<LOGN2, true, false>), grid, dim3(1 << LOGN2), 0, s, scratch, data, half2, g.logn1, inv_n);
+  else hipLaunchKernelGGL((k_big2_rows<LOGN2, false, false>), grid, dim3(1 << LOGN2), 0, s, scratch, data, half2, g.logn1, inv_n);
+  return hipGetLastError();
+}
+static hipError_t launch_fft_big2(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, const cpx *bigtabs,
+                                  const FftTables &sub, long batch, hipStream_t s) {
+  hipError_t e;
+  switch (g.logn1) {
+    case 8: e = launch_big2_cols<8>(g, fwd, data, scratch, bigtabs, batch, s); break;
+    case 9: e = launch_big2_cols<9>(g, fwd, data, scratch, bigtabs, batch, s); break;
+    case 10: e = launch_big2_cols<10>(g, fwd, data, scratch, bigtabs, batch, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  switch (g.logn2) {
+    case 9: return launch_big2_rows<9>(g, fwd, scale, scratch, data, sub.half, batch, s);
+    case 10: return launch_big2_rows<10>(g, fwd, scale, scratch, data, sub.half, batch, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 // scratch: `batch` transforms (the caller chunks); scratch2: the four-step workspace when N2 > 8192
 hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, cpx *scratch2,
                           const cpx *bigtabs, const FftTables &sub, long batch, const DeviceInfo &di, hipStream_t s) {
   if (batch <= 0) return hipSuccess;
   if (batch > 65535) return hipErrorInvalidValue;
+  if (g.logn <= 20) return launch_fft_big2(g, fwd, scale, data, scratch, bigtabs, sub, batch, s);
   switch (g.logn1) {
     case 5: return launch_big_n1<5>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
     case 6: return launch_big_n1<6>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
