@@ -92,6 +92,24 @@ void fill_fourstep_tables(std::vector<cpx> &all, int logn) {
   all.insert(all.end(), part.begin(), part.begin() + hi);
 }
 
+// host tables of the resident n = 65536 kernel (internal.hpp, kRes16TabSize), each value rounded from
+// double like the reference's table (cl_fft.cpp:89-90)
+void fill_res16_tables(std::vector<cpx> &all) {
+  all.clear();
+  std::vector<cpx> part;
+  for (int t = 0; t < 16; t++)
+    for (int j = 0; j < 16; j++) all.push_back(mk((float)cos((t * j) * 2 * kPI / 256), -(float)sin((t * j) * 2 * kPI / 256)));
+  fill_twiddle(part, 256, 65536, 1, -1.f);
+  all.insert(all.end(), part.begin(), part.begin() + 256);
+  fill_twiddle(part, 256, 256, 1, -1.f);
+  all.insert(all.end(), part.begin(), part.begin() + 256);
+  for (int m = 1; m <= 8; m *= 2)
+    for (int k = 0; k < 256; k++) {
+      const int idx = (m * k) & 4095;
+      all.push_back(mk((float)cos(idx * 2 * kPI / 4096), -(float)sin(idx * 2 * kPI / 4096)));
+    }
+}
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -181,7 +199,7 @@ struct clfa_fft {
   int variant = 0;
   char log[2048];
   hipStream_t stream = nullptr;
-  DevBuf half, w2, four, scratch, stage, ctl;
+  DevBuf half, w2, four, scratch, stage, ctl, res16;
   HostBuf zstage;        // zero-copy staging of small host transforms
   FftTables tabs;
   // n > 65536 (extension): n = N1 x N2; `tabs` then belongs to the N2-point row transform
@@ -360,6 +378,10 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     fill_fourstep_tables(all, rowlog);
     if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
     p->tabs.four = (const cpx *)p->four.p;
+    if (rowlog == 16) {
+      fill_res16_tables(all);
+      if ((e = upload(p->res16, all.data(), sizeof(cpx) * all.size()))) return e;
+    }
     size_t sbytes = (size_t)fourstep_grid(rowlog, p->variant, p->di) * rown * sizeof(cpx);
     if (p->variant == kVariantCoop) sbytes = coop_scratch_bytes(rowlog);
     DevBuf &ws = p->logn > kMaxLog ? p->scratch2 : p->scratch;
@@ -411,6 +433,7 @@ void clfa_fft_destroy(clfa_fft *p) {
   p->scratch.release();
   p->stage.release();
   p->ctl.release();
+  p->res16.release();
   p->zstage.release();
   p->bigtabs.release();
   p->scratch2.release();
@@ -485,6 +508,8 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
     HIP_TRY(launch_fft_coop(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));
   else if (p->variant == kVariantCoop2)
     HIP_TRY(launch_fft_coop2(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));
+  else if (p->logn == 16 && p->variant == 0 && batch * 4 > p->di.num_cus && !getenv("CLFA_NO_RES16"))
+    HIP_TRY(launch_fft_res16(p->fwd, scale, d, (cpx *)p->scratch.p, (const cpx *)p->res16.p, batch, p->di, s));
   else
     HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, p->variant, d, (cpx *)p->scratch.p, p->tabs, batch, p->di, s));
   if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, p->n, batch, s));

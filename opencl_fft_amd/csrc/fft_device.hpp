@@ -61,22 +61,49 @@ CLFA_HD cpx csub(cpx a, cpx b) { return mk(a.x - b.x, a.y - b.y); }
 CLFA_HD cpx cscale(cpx a, float s) { return mk(a.x * s, a.y * s); }
 #endif
 CLFA_HD cpx cconj(cpx a) { return mk(a.x, -a.y); }
-// a * b, or a * conj(b)
+// a * b, or a * conj(b).  The two instructions sit in ONE asm statement: hipcc pads every statement
+// whose result the next instruction reads with an s_nop (it cannot see that this is a plain VALU
+// dependency), which cost one issue slot per complex multiply.
 template <bool CONJ = false> CLFA_HD cpx cmulc(cpx a, cpx b) {
 #if CLFA_PK
-  cpx t, r;
+  cpx r;
   if (!CONJ) {
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                      // (ax bx, ax by)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"               // (-ay by, ay bx) + t
-        : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"                                                // (ax bx, ax by)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                  // (-ay by, ay bx) + t
+        : "=&v"(r) : "v"(a), "v"(b));
   } else {
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));         // (ax bx, -ax by)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"                              // (ay by, ay bx) + t
-        : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"                                   // (ax bx, -ax by)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"                                 // (ay by, ay bx) + t
+        : "=&v"(r) : "v"(a), "v"(b));
   }
   return r;
 #else
   return CONJ ? mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y) : mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
+}
+// two independent products in one statement, interleaved (mul, mul, fma, fma): no dependent
+// back-to-back issue and one statement boundary for four instructions
+template <bool CONJ = false> CLFA_HD void cmulc2(cpx &r0, cpx &r1, cpx a0, cpx b0, cpx a1, cpx b1) {
+#if CLFA_PK
+  cpx x, y;
+  if (!CONJ) {
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(x), "=&v"(y) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+  } else {
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(x), "=&v"(y) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+  }
+  r0 = x;
+  r1 = y;
+#else
+  r0 = cmulc<CONJ>(a0, b0);
+  r1 = cmulc<CONJ>(a1, b1);
 #endif
 }
 CLFA_HD cpx cmul(cpx a, cpx b) { return cmulc<false>(a, b); }
@@ -97,17 +124,46 @@ template <bool FWD> CLFA_HD cpx add_rot(cpx x, cpx y) {
 #endif
 }
 template <bool FWD> CLFA_HD cpx sub_rot(cpx x, cpx y) { return add_rot<!FWD>(x, y); }
-// constant twiddle (c, -s) forward / (c, +s) inverse: a*c + rot4(a)*s
+// constant twiddle (c, -s) forward / (c, +s) inverse: a*c + rot4(a)*s (one statement, see cmulc)
 template <bool FWD> CLFA_HD cpx ctw(cpx a, float c, float s) {
 #if CLFA_PK
   const cpx k = mk(c, s);   // compile-time constants: an SGPR pair
-  cpx t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(k));                                      // (ax c, ay c)
-  if (FWD) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(k), "v"(t));  // (ay s, -ax s) + t
-  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(k), "v"(t));      // (-ay s, ax s) + t
+  cpx r;
+  if (FWD)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"                                                 // (ax c, ay c)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"                   // (ay s, -ax s) + t
+        : "=&v"(r) : "v"(a), "s"(k));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"                   // (-ay s, ax s) + t
+        : "=&v"(r) : "v"(a), "s"(k));
   return r;
 #else
   return FWD ? mk(a.x * c + a.y * s, a.y * c - a.x * s) : mk(a.x * c - a.y * s, a.y * c + a.x * s);
+#endif
+}
+// two constant twiddles, interleaved
+template <bool FWD> CLFA_HD void ctw2(cpx &a0, float c0, float s0, cpx &a1, float c1, float s1) {
+#if CLFA_PK
+  const cpx k0 = mk(c0, s0), k1 = mk(c1, s1);
+  cpx x, y;
+  if (FWD)
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(x), "=&v"(y) : "v"(a0), "s"(k0), "v"(a1), "s"(k1));
+  else
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=&v"(x), "=&v"(y) : "v"(a0), "s"(k0), "v"(a1), "s"(k1));
+  a0 = x;
+  a1 = y;
+#else
+  a0 = ctw<FWD>(a0, c0, s0);
+  a1 = ctw<FWD>(a1, c1, s1);
 #endif
 }
 
@@ -172,16 +228,11 @@ template <int U, int E, bool FWD> CLFA_HD void dft16(cpx (&v)[E], int u) {
   for (int t = 0; t < 16; t++) x[t] = v[u + U * t];
 #pragma unroll
   for (int b = 0; b < 4; b++) bf4<FWD>(x[b], x[4 + b], x[8 + b], x[12 + b]);  // -> x[4*q0 + b]
-  // W_16^(b*q0)
-  x[4 + 1] = ctw<FWD>(x[4 + 1], kC16, kS16);    // 1
-  x[4 + 2] = ctw<FWD>(x[4 + 2], kC8, kC8);      // 2
-  x[4 + 3] = ctw<FWD>(x[4 + 3], kS16, kC16);    // 3
-  x[8 + 1] = ctw<FWD>(x[8 + 1], kC8, kC8);      // 2
-  //                                               4: rot4, folded into bf4_rot2 below
-  x[8 + 3] = ctw<FWD>(x[8 + 3], -kC8, kC8);     // 6
-  x[12 + 1] = ctw<FWD>(x[12 + 1], kS16, kC16);  // 3
-  x[12 + 2] = ctw<FWD>(x[12 + 2], -kC8, kC8);   // 6
-  x[12 + 3] = ctw<FWD>(x[12 + 3], -kC16, -kS16);// 9
+  // W_16^(b*q0), two per statement (W_16^4 = rot4 is folded into bf4_rot2 below)
+  ctw2<FWD>(x[4 + 1], kC16, kS16, x[4 + 2], kC8, kC8);        // 1, 2
+  ctw2<FWD>(x[4 + 3], kS16, kC16, x[8 + 1], kC8, kC8);        // 3, 2
+  ctw2<FWD>(x[8 + 3], -kC8, kC8, x[12 + 1], kS16, kC16);      // 6, 3
+  ctw2<FWD>(x[12 + 2], -kC8, kC8, x[12 + 3], -kC16, -kS16);   // 6, 9
 #pragma unroll
   for (int q0 = 0; q0 < 4; q0++) {
     if (q0 == 2) bf4_rot2<FWD>(x[8], x[9], x[10], x[11]);

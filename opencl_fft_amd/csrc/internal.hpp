@@ -39,6 +39,14 @@ hipError_t launch_fft_4step(int logn, bool fwd, bool scale, int variant, cpx *da
                             const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
 const char *name_fft_4step(int logn, bool fwd, int variant);
 int fourstep_split(int logn, int *logn1, int *logn2, int *loglo);
+// n = 65536, the whole intermediate resident on the CU (fft_resident.hip): one HBM pass, no scratch.
+// tabs: kRes16TabSize entries, forward sign: [W_256^(t j), t, j < 16 | W_n^k, k < 256 | W_256^k, k < 256 |
+// W_4096^(m k mod 4096), m = 1, 2, 4, 8, k < 256]
+constexpr int kRes16TabSize = 1792;
+// slots: 32 KiB per workgroup, grid = min(batch, CUs) workgroups (kRes16SlotBytes each)
+constexpr size_t kRes16SlotBytes = 32768;
+hipError_t launch_fft_res16(bool fwd, bool scale, cpx *data, cpx *slots, const cpx *tabs, long batch,
+                            const DeviceInfo &di, hipStream_t s);
 // XCD-cooperative four-step (variant 7; selectable, slower than the default): scratch = 8 XCDs x slots x n complex,
 // ctl = a small control block zeroed on the stream before every launch
 constexpr int kVariantCoop = 7;

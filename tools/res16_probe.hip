@@ -1,0 +1,78 @@
+// dev tool (not product): where the resident n = 65536 kernel spends its time.
+//   hipcc -std=c++17 -O3 --offload-arch=gfx950 -fno-slp-vectorize -I opencl_fft_amd/csrc tools/res16_probe.hip -o /tmp/res16_probe
+// Times k_fft_res16 on 4096 transforms with parts left out (PROBE bits, fft_resident.hip) and reads the
+// per-phase clock stamps.  Results are garbage by construction for every mode but "full".
+#include "../opencl_fft_amd/csrc/fft_resident.hip"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace clfa;
+
+#define CK(x)                                                         \
+  do {                                                                \
+    hipError_t e = (x);                                               \
+    if (e != hipSuccess) {                                            \
+      printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); \
+      exit(1);                                                        \
+    }                                                                 \
+  } while (0)
+
+template <int PROBE> static void run(const char *name, cpx *data, cpx *slots, cpx *tabs, unsigned long long *dbg, long batch, int cus) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int warm = 10, reps = 40;
+  for (int i = 0; i < warm; i++) hipLaunchKernelGGL((k_fft_res16<true, false, PROBE>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, dbg);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_fft_res16<true, false, PROBE>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, dbg);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  double p1 = 0, p2 = 0;
+  if (PROBE & kProbeStamps) {
+    std::vector<unsigned long long> h(2 * cus);
+    CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < cus; i++) {
+      p1 += h[2 * i];
+      p2 += h[2 * i + 1];
+    }
+    p1 /= cus;
+    p2 /= cus;
+  }
+  printf("%-34s %8.3f ms  %6.2f TB/s alg", name, ms, batch * 65536.0 * 16 / ms * 1e-9);
+  if (PROBE & kProbeStamps) printf("   phase1 %.1f  phase2 %.1f  kcycles per transform (s_memtime, 100 MHz ticks x?)", p1 / (batch / cus) * 1e-3, p2 / (batch / cus) * 1e-3);
+  printf("\n");
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  const long batch = 4096;
+  cpx *data, *slots, *tabs;
+  unsigned long long *dbg;
+  CK(hipMalloc(&data, batch * 65536 * 8));
+  CK(hipMalloc(&slots, (size_t)cus * 32768));
+  CK(hipMalloc(&tabs, 1792 * 8));
+  CK(hipMalloc(&dbg, cus * 16));
+  CK(hipMemset(data, 0, batch * 65536 * 8));
+  std::vector<cpx> t(1792);
+  for (int i = 0; i < 1792; i++) t[i] = mk((float)cos(i * 0.001), (float)sin(i * 0.001));   // unit-modulus stand-ins: timing only
+  CK(hipMemcpy(tabs, t.data(), 1792 * 8, hipMemcpyHostToDevice));
+  printf("k_fft_res16 probe: %ld transforms, %d workgroups\n", batch, cus);
+  run<0>("full", data, slots, tabs, dbg, batch, cus);
+  run<16>("full + stamps", data, slots, tabs, dbg, batch, cus);
+  run<1 | 16>("no loads", data, slots, tabs, dbg, batch, cus);
+  run<2 | 16>("no stores", data, slots, tabs, dbg, batch, cus);
+  run<8 | 16>("no slot traffic", data, slots, tabs, dbg, batch, cus);
+  run<1 | 2 | 8 | 16>("no global traffic at all", data, slots, tabs, dbg, batch, cus);
+  run<1 | 2 | 8 | 4 | 16>("no global traffic, no barriers", data, slots, tabs, dbg, batch, cus);
+  run<4 | 16>("no barriers", data, slots, tabs, dbg, batch, cus);
+  run<0>("full (again)", data, slots, tabs, dbg, batch, cus);
+  return 0;
+}
