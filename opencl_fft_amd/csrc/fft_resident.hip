@@ -1,29 +1,44 @@
-// fft_resident.hip — n = 65536 complex, one HBM pass, nothing but the input and the output ever
-// leaves the compute unit.
+// fft_resident.hip — n = 65536 complex in one HBM pass: the intermediate of the four-step transform
+// stays on the compute unit.
 //
 // Replaces the reference's reorder + 16 stage launches for N = 65536 (cl_fft.cpp:24-41, 138-151).
 //
 // The transform is N1 x N2 = 256 x 256 (four-step): phase 1 = 256-point FFTs down the columns of the
 // row-major input times W_N^(n2 k1), phase 2 = 256-point FFTs along the rows, stored transposed
-// (X[k1 + 256 k2]).  512 KiB per transform do not fit the 160 KiB of LDS — but they do fit the compute
-// unit: ONE 256-lane workgroup per CU (one wave per SIMD) owns the whole 512-entry register file
-// of every lane (256 arch VGPRs + 256 accumulation VGPRs).
+// (X[k1 + 256 k2]).  512 KiB per transform do not fit the 160 KiB of LDS — but they (almost) fit the
+// compute unit: ONE 256-lane workgroup per CU (one wave per SIMD) owns the whole 512-entry register
+// file of every lane (256 arch VGPRs + 256 accumulation VGPRs).
 //
-// Lane l = c + 16 t.  Phase 1, column block cb (16 columns, 128-byte row segments): the lane loads
+// Lane l = c + 16 t.  Phase 1, column block cb (16 columns, 128-byte row segments): the lane takes
 // rows t + 16 e of column n2 = 16 cb + c, and after the two radix-16 passes (one LDS exchange) it
 // holds Z[k1 = t + 16 e][n2].  Phase 2, row block rb (16 rows): the lane that works on row
 // k1 = 16 rb + t at positions n2 = c + 16 e needs exactly Z[16 rb + t][16 e + c], e = 0..15 — the
 // values this very lane produced for e = rb in column blocks cb = 0..15.  So the intermediate never
 // changes lanes: every lane keeps a private 16 x 16 matrix keep[rb][cb] of complex values
 //   rb 0..2   in LDS          (lane-private spill area, 400 bytes per lane)
-//   rb 3      in a 32 KiB per-workgroup global slot (L2-resident: 8 MiB for the whole chip) — the one
-//             sixteenth that the register file cannot take next to the working registers
+//   rb 3      in a 32 KiB per-workgroup global slot (8 MiB for the whole chip, read back from L2) — the
+//             one sixteenth that the register file cannot take next to the working registers
 //   rb 4..7   in arch VGPRs   (four 32-float vectors, written through s_set_gpr_idx)
-//   rb 8..15  in AGPRs        (a[32 (rb-8) + 2 cb], written / read by v_accvgpr moves with literal
-//                              register numbers inside a uniform switch: nothing the compiler
-//                              allocates lives in the accumulation file)
+//   rb 8..15  in AGPRs        (a[32 (rb-8) + 2 cb], moved by v_accvgpr_* with literal register
+//                              numbers inside a uniform switch)
 // and no hand-over between the phases exists at all.  Fabric traffic is the algorithmic 16 bytes per
-// sample plus the slot's 0.5 (written through) and at most 0.5 (read back, normally from L2).
+// sample plus the slot's 0.5 (written through) and at most 0.5 (read back).
+//
+// What one wave per SIMD costs, and what the kernel does about it (tools/res16_probe.hip measures every
+// item; profiles/res16_probe_r02.txt):
+//   * nothing else runs while the wave waits, so a block's 16 loads / stores cannot be issued back
+//     to back (each then waits ~80 cycles for a queue slot): they ride along the arithmetic, one per
+//     hook point (16 per block, ~20 instructions apart) — the loads of the column block TWO ahead in
+//     phase 1, the stores of the PREVIOUS row block in phase 2;
+//   * those loads need somewhere to land that hipcc does not touch (it copies "its" registers
+//     whenever it likes, also while a load is still pending on them): even column blocks land in AGPR
+//     columns of the keep matrix that are still empty, odd ones in v[224:255] — the kernel is compiled
+//     with amdgpu_num_vgpr(224), so the register allocator never sees those; the same registers park
+//     a row block's results in phase 2 until their stores have been issued;
+//   * hipcc counts none of that traffic: every wait is an explicit s_waitcnt vmcnt(N), N = the asm
+//     loads issued after the awaited ones.
+// tools/check_isa.py audits the code object (no compiler-generated AGPR moves, no compiler instruction
+// on v[224:255], no scratch); tests/test_abi_cpu.py runs it on every build.
 //
 // Global accesses are buffer_load/store_dwordx2 ... offen nt with the row offsets e * 32 KiB in
 // SGPRs: one instruction per access, no address arithmetic.  Both LDS exchanges write 8 x b128 and
@@ -32,6 +47,7 @@
 // product tree (15 complex multiplies for 16 values); the forward 1/N rides on the table of b.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "internal.hpp"
@@ -71,16 +87,26 @@ __device__ __forceinline__ void acc_claim_all() {
                CLFA_A10(4), CLFA_A10(5), CLFA_A10(6), CLFA_A10(7), CLFA_A10(8), CLFA_A10(9), CLFA_A10(10), CLFA_A10(11),
                CLFA_A10(12), CLFA_A10(13), CLFA_A10(14), CLFA_A10(15), CLFA_A10(16), CLFA_A10(17), CLFA_A10(18),
                CLFA_A10(19), CLFA_A10(20), CLFA_A10(21), CLFA_A10(22), CLFA_A10(23), CLFA_A10(24), "a250", "a251", "a252",
-               "a253", "a254", "a255");
+               "a253", "a254", "a255",
+               // ... and the landing registers v[224:255] (kept out of hipcc's hands by amdgpu_num_vgpr(224))
+               "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237",
+               "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251",
+               "v252", "v253", "v254", "v255");
 }
 #undef CLFA_A10
-// column block CB: element e = 8 + J of the lane's results goes to a[32 J + 2 CB]
+// Two AGPR column pairs double as landing zones for the even column blocks' loads while they are
+// still empty: Z0 = columns 14, 15 (blocks 0, 4, 8, 12), Z1 = columns 12, 13 (blocks 2, 6, 10, 14).
+// They fall free in the order Z0 (block 12 taken out), Z1 (block 14 taken out), so the keep matrix's
+// columns 12..15 are stored swapped: logical column c lives in physical column acc_col(c).
+constexpr int kZone0 = 14, kZone1 = 12;
+constexpr int acc_col(int c) { return c < 12 ? c : c ^ 2; }
+// column block CB: element e = 8 + J of the lane's results goes to a[32 J + 2 acc_col(CB)]
 template <int CB, int... J> __device__ __forceinline__ void acc_deposit(const cpx (&o)[16], std::integer_sequence<int, J...>) {
-  ((acc_write<32 * J + 2 * CB>(o[kAgprFirst + J].x), acc_write<32 * J + 2 * CB + 1>(o[kAgprFirst + J].y)), ...);
+  ((acc_write<32 * J + 2 * acc_col(CB)>(o[kAgprFirst + J].x), acc_write<32 * J + 2 * acc_col(CB) + 1>(o[kAgprFirst + J].y)), ...);
 }
-// row block 8 + RB: a[32 RB + 2 e] -> v[e]
+// row block 8 + RB: a[32 RB + 2 acc_col(e)] -> v[e]
 template <int RB, int... E> __device__ __forceinline__ void acc_fetch(cpx (&v)[16], std::integer_sequence<int, E...>) {
-  ((v[E].x = acc_read<32 * RB + 2 * E>(), v[E].y = acc_read<32 * RB + 2 * E + 1>()), ...);
+  ((v[E].x = acc_read<32 * RB + 2 * acc_col(E)>(), v[E].y = acc_read<32 * RB + 2 * acc_col(E) + 1>()), ...);
 }
 
 // ---- global accesses ----------------------------------------------------------------------------
@@ -91,22 +117,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const cpx *base) {
 // PROBE (tools/res16_probe.hip only; the library instantiates 0): timing experiments that leave parts
 // of the kernel out — 1 no global loads, 2 no global stores, 4 no barriers, 8 no slot traffic,
 // 16 per-phase clock stamps into `dbg`
-enum { kProbeNoLoad = 1, kProbeNoStore = 2, kProbeNoBarrier = 4, kProbeNoSlot = 8, kProbeStamps = 16 };
+//   32 loads issued but never waited for, 64 no arithmetic (exchanges, barriers and memory traffic only),
+//   128 phase 1 only (phase 2 skipped), 256 each workgroup starts its address sequence at another
+//   column block (blockIdx rotates the 128-byte column offset; results are then garbage)
+enum { kProbeNoLoad = 1, kProbeNoStore = 2, kProbeNoBarrier = 4, kProbeNoSlot = 8, kProbeStamps = 16,
+       kProbeNoWait = 32, kProbeNoMath = 64, kProbePhase1Only = 128, kProbeRotate = 256, kProbeGridSync = 512 };
+//   512 a grid-wide barrier at every phase boundary (counter at dbg[1024]; the stamps exclude the wait):
+//   what perfectly aligned read and write phases would be worth
 template <int PROBE> __device__ __forceinline__ void res_barrier() {
   if constexpr (!(PROBE & kProbeNoBarrier)) __syncthreads();
 }
 // 16 rows 16 apart (32 KiB), lane offset `voff` bytes; non-temporal (aux 2)
-template <int PROBE = 0> __device__ __forceinline__ void res_load(cpx (&v)[16], __amdgpu_buffer_rsrc_t r, int voff) {
-#pragma unroll
-  for (int e = 0; e < 16; e++) {
-    if constexpr (PROBE & kProbeNoLoad) {
-      asm volatile("" : "+v"(v[e]));
-    } else {
-      const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, e * 32768, 2);
-      v[e] = __builtin_bit_cast(cpx, raw);
-    }
-  }
-}
 template <int PROBE = 0> __device__ __forceinline__ void res_store(const cpx (&v)[16], __amdgpu_buffer_rsrc_t r, int voff) {
 #pragma unroll
   for (int e = 0; e < 16; e++) {
@@ -119,23 +140,220 @@ template <int PROBE = 0> __device__ __forceinline__ void res_store(const cpx (&v
   }
 }
 
+// ---- loads the compiler does not see ---------------------------------------------------------------
+// Phase 1 keeps TWO column blocks in flight (64 KiB per CU: one block ahead is latency-bound, see
+// DESIGN.md), and there are no 32 spare VGPRs for the second one.  It lands in the accumulation
+// registers of the keep matrix's columns cb and cb + 1, which are still empty while block cb waits
+// (rows e < 8 -> a[32 e + 2 cb], rows e >= 8 -> a[32 (e - 8) + 2 (cb + 1)]); blocks with odd cb land
+// in reserved VGPRs (below).  hipcc counts neither kind (all are asm), so the waits are explicit: s_waitcnt vmcnt(N) with
+// N = the asm loads issued after the awaited ones (compiler-issued stores in between only make the
+// wait stronger).  The s_nop 4 covers SALU-written descriptor / offset SGPRs read by VMEM.
+template <int COL, int E0> __device__ __forceinline__ void res_load_acc8(__amdgpu_buffer_rsrc_t r, int voff) {
+#define CLFA_LD "buffer_load_dwordx2 a[%c"
+  asm volatile("s_nop 4\n\t"
+               "buffer_load_dwordx2 a[%c2:%c3], %0, %1, %18 offen nt\n\t"
+               "buffer_load_dwordx2 a[%c4:%c5], %0, %1, %19 offen nt\n\t"
+               "buffer_load_dwordx2 a[%c6:%c7], %0, %1, %20 offen nt\n\t"
+               "buffer_load_dwordx2 a[%c8:%c9], %0, %1, %21 offen nt\n\t"
+               "buffer_load_dwordx2 a[%c10:%c11], %0, %1, %22 offen nt\n\t"
+               "buffer_load_dwordx2 a[%c12:%c13], %0, %1, %23 offen nt\n\t"
+               "buffer_load_dwordx2 a[%c14:%c15], %0, %1, %24 offen nt\n\t"
+               "buffer_load_dwordx2 a[%c16:%c17], %0, %1, %25 offen nt"
+               :
+               : "v"(voff), "s"(r), "n"(0 * 32 + 2 * COL), "n"(0 * 32 + 2 * COL + 1), "n"(1 * 32 + 2 * COL),
+                 "n"(1 * 32 + 2 * COL + 1), "n"(2 * 32 + 2 * COL), "n"(2 * 32 + 2 * COL + 1), "n"(3 * 32 + 2 * COL),
+                 "n"(3 * 32 + 2 * COL + 1), "n"(4 * 32 + 2 * COL), "n"(4 * 32 + 2 * COL + 1), "n"(5 * 32 + 2 * COL),
+                 "n"(5 * 32 + 2 * COL + 1), "n"(6 * 32 + 2 * COL), "n"(6 * 32 + 2 * COL + 1), "n"(7 * 32 + 2 * COL),
+                 "n"(7 * 32 + 2 * COL + 1), "s"((E0 + 0) * 32768), "s"((E0 + 1) * 32768), "s"((E0 + 2) * 32768),
+                 "s"((E0 + 3) * 32768), "s"((E0 + 4) * 32768), "s"((E0 + 5) * 32768), "s"((E0 + 6) * 32768),
+                 "s"((E0 + 7) * 32768)
+               : "memory");
+#undef CLFA_LD
+}
+// one column block (at `base`) -> AGPR columns ZC, ZC + 1, all 16 loads at once
+template <int ZC> __device__ __forceinline__ void res_load_acc(const cpx *base, int voff) {
+  const __amdgpu_buffer_rsrc_t r = res_rsrc(base);
+  res_load_acc8<ZC, 0>(r, voff);
+  res_load_acc8<ZC + 1, 8>(r, voff);
+}
+// ... and back out, once its wait has passed
+template <int CB, int... E> __device__ __forceinline__ void acc_fetch_raw(cpx (&v)[16], std::integer_sequence<int, E...>) {
+  ((v[E].x = acc_read<32 * E + 2 * CB>(), v[E].y = acc_read<32 * E + 2 * CB + 1>()), ...);
+  ((v[8 + E].x = acc_read<32 * E + 2 * CB + 2>(), v[8 + E].y = acc_read<32 * E + 2 * CB + 3>()), ...);
+}
+// Blocks with odd cb land in v[224:255].  The kernel is compiled with amdgpu_num_vgpr(224), so hipcc
+// allocates v0..v223 only and never reads, copies or spills a register with a load still pending on it
+// (with compiler-allocated destinations it did: it moved them ahead of the wait).
+template <int E0> __device__ __forceinline__ void res_load_land8(__amdgpu_buffer_rsrc_t r, int voff) {
+  asm volatile("s_nop 4\n\t"
+               "buffer_load_dwordx2 v[%c2:%c3], %0, %1, %18 offen nt\n\t"
+               "buffer_load_dwordx2 v[%c4:%c5], %0, %1, %19 offen nt\n\t"
+               "buffer_load_dwordx2 v[%c6:%c7], %0, %1, %20 offen nt\n\t"
+               "buffer_load_dwordx2 v[%c8:%c9], %0, %1, %21 offen nt\n\t"
+               "buffer_load_dwordx2 v[%c10:%c11], %0, %1, %22 offen nt\n\t"
+               "buffer_load_dwordx2 v[%c12:%c13], %0, %1, %23 offen nt\n\t"
+               "buffer_load_dwordx2 v[%c14:%c15], %0, %1, %24 offen nt\n\t"
+               "buffer_load_dwordx2 v[%c16:%c17], %0, %1, %25 offen nt"
+               :
+               : "v"(voff), "s"(r), "n"(224 + 2 * E0), "n"(225 + 2 * E0), "n"(226 + 2 * E0), "n"(227 + 2 * E0),
+                 "n"(228 + 2 * E0), "n"(229 + 2 * E0), "n"(230 + 2 * E0), "n"(231 + 2 * E0), "n"(232 + 2 * E0),
+                 "n"(233 + 2 * E0), "n"(234 + 2 * E0), "n"(235 + 2 * E0), "n"(236 + 2 * E0), "n"(237 + 2 * E0),
+                 "n"(238 + 2 * E0), "n"(239 + 2 * E0), "s"((E0 + 0) * 32768), "s"((E0 + 1) * 32768),
+                 "s"((E0 + 2) * 32768), "s"((E0 + 3) * 32768), "s"((E0 + 4) * 32768), "s"((E0 + 5) * 32768),
+                 "s"((E0 + 6) * 32768), "s"((E0 + 7) * 32768)
+               : "memory");
+}
+__device__ __forceinline__ void res_load_land(const cpx *base, int voff) {
+  const __amdgpu_buffer_rsrc_t r = res_rsrc(base);
+  res_load_land8<0>(r, voff);
+  res_load_land8<8>(r, voff);
+}
+// ... and out of the landing registers (after the wait)
+__device__ __forceinline__ void res_land_fetch(cpx (&v)[16]) {
+  asm volatile("v_mov_b64 %0, v[224:225]\n\tv_mov_b64 %1, v[226:227]\n\tv_mov_b64 %2, v[228:229]\n\tv_mov_b64 %3, v[230:231]\n\t"
+               "v_mov_b64 %4, v[232:233]\n\tv_mov_b64 %5, v[234:235]\n\tv_mov_b64 %6, v[236:237]\n\tv_mov_b64 %7, v[238:239]"
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]));
+  asm volatile("v_mov_b64 %0, v[240:241]\n\tv_mov_b64 %1, v[242:243]\n\tv_mov_b64 %2, v[244:245]\n\tv_mov_b64 %3, v[246:247]\n\t"
+               "v_mov_b64 %4, v[248:249]\n\tv_mov_b64 %5, v[250:251]\n\tv_mov_b64 %6, v[252:253]\n\tv_mov_b64 %7, v[254:255]"
+               : "=v"(v[8]), "=v"(v[9]), "=v"(v[10]), "=v"(v[11]), "=v"(v[12]), "=v"(v[13]), "=v"(v[14]), "=v"(v[15]));
+}
+// waits for the asm loads: N = the asm loads issued after the awaited ones
+template <int N> __device__ __forceinline__ void res_wait_vm() {
+  static_assert(N == 0 || N == 16 || N == 32 || N == 48, "");
+  if constexpr (N == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+}
+
 __device__ __forceinline__ f4 pack2(cpx a, cpx b) { return f4{a.x, a.y, b.x, b.y}; }
 
-// second radix-16 pass of a 256-point transform: inputs times W_256^(t j) (row t of the table), then
-// the butterflies
-template <bool FWD> __device__ __forceinline__ void twiddled_dft16(cpx (&v)[16], const cpx *tw_row) {
-  const f4 *pt = reinterpret_cast<const f4 *>(tw_row);
-  {
-    const f4 w = pt[0];
-    v[1] = cmulc<!FWD>(v[1], mk(w.z, w.w));
+// ---- loads interleaved with the arithmetic ---------------------------------------------------------
+// One wave per SIMD cannot afford to issue a block's 16 loads back to back: with the memory pipeline
+// saturated every load instruction then waits ~80 cycles for a queue slot, and nothing else runs on
+// that SIMD meanwhile (measured: the loads cost the same whether or not anything waits for their
+// data, profiles/res16_probe_r02.txt).  So a column block's code has 16 hook points, ~20 instructions
+// apart, and each issues ONE load of the block two ahead.  so[e] = e * 32 KiB, pinned in SGPRs.
+template <int K> using ic = std::integral_constant<int, K>;
+struct HookNone {
+  template <int K> __device__ __forceinline__ void operator()(ic<K>) const {}
+};
+template <int CB> struct HookAcc {   // -> AGPR columns CB, CB + 1 (a landing zone)
+  __amdgpu_buffer_rsrc_t r;
+  int voff;
+  const int (&so)[16];
+  template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
+    constexpr int lo = 32 * (K & 7) + 2 * (K < 8 ? CB : CB + 1);
+    if constexpr (K == 0)   // the descriptor's SGPRs may be fresh from SALU: 5 wait states before VMEM reads them
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
+    else
+      asm volatile("buffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
   }
-#pragma unroll
-  for (int i = 1; i < 8; i++) {
-    const f4 w = pt[i];
-    cmulc2<!FWD>(v[2 * i], v[2 * i + 1], v[2 * i], mk(w.x, w.y), v[2 * i + 1], mk(w.z, w.w));
+};
+struct HookLand {   // -> landing registers v[224:255]
+  __amdgpu_buffer_rsrc_t r;
+  int voff;
+  const int (&so)[16];
+  template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
+    if constexpr (K == 0)
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+    else
+      asm volatile("buffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
   }
-  dft16<1, 16, FWD>(v, 0);
+};
+// block 15 of phase 1 has nothing left to prefetch: its hooks bring the global slot's row block back
+// (columns 0..14; column 15 is still in the lane's registers then) into v[224:253]; agent scope (sc1): the
+// loads bypass this CU's L1, which may still hold the previous transform's lines
+struct HookSlot {
+  __amdgpu_buffer_rsrc_t r;
+  int voff;
+  const int (&so)[16];
+  template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
+    if constexpr (K < 15) {
+      int off;
+      asm volatile("s_lshr_b32 %0, %3, 4\n\ts_nop 4\n\tbuffer_load_dwordx2 v[%c4:%c5], %1, %2, %0 offen sc1"
+                   : "=&s"(off)
+                   : "v"(voff), "s"(r), "s"(so[K]), "n"(224 + 2 * K), "n"(225 + 2 * K)
+                   : "memory", "scc");
+    }
+  }
+};
+// phase 2: a row block's 16 stores ride along the NEXT block's arithmetic, out of the landing registers
+// (idle in phase 2), where res_stage() has put the block's results
+struct HookStore {
+  __amdgpu_buffer_rsrc_t r;
+  int voff;
+  const int (&so)[16];
+  template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
+    if constexpr (K == 0)
+      asm volatile("s_nop 4\n\tbuffer_store_dwordx2 v[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+    else
+      asm volatile("buffer_store_dwordx2 v[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+  }
+};
+__device__ __forceinline__ void res_stage(const cpx (&v)[16]) {
+  asm volatile("v_mov_b64 v[224:225], %0\n\tv_mov_b64 v[226:227], %1\n\tv_mov_b64 v[228:229], %2\n\tv_mov_b64 v[230:231], %3\n\t"
+               "v_mov_b64 v[232:233], %4\n\tv_mov_b64 v[234:235], %5\n\tv_mov_b64 v[236:237], %6\n\tv_mov_b64 v[238:239], %7"
+               ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+  asm volatile("v_mov_b64 v[240:241], %0\n\tv_mov_b64 v[242:243], %1\n\tv_mov_b64 v[244:245], %2\n\tv_mov_b64 v[246:247], %3\n\t"
+               "v_mov_b64 v[248:249], %4\n\tv_mov_b64 v[250:251], %5\n\tv_mov_b64 v[252:253], %6\n\tv_mov_b64 v[254:255], %7"
+               ::"v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
 }
+__device__ __forceinline__ void res_stage_one15(cpx o) { asm volatile("v_mov_b64 v[254:255], %0" ::"v"(o)); }
+
+// hook-point maps: eight local points of dft16_h -> global hook numbers (-1: none)
+struct HookMap {
+  int p[8];
+};
+constexpr HookMap kMapColA{{0, -1, 1, -1, 2, -1, 3, -1}};      // column block, first pass: hooks 0..3
+constexpr HookMap kMapColB{{8, -1, 9, -1, 10, -1, 11, -1}};    // ... second pass: hooks 8..11 (4..7: twiddles, 12..15: four-step)
+constexpr HookMap kMapRowC{{0, 1, 2, -1, 3, 4, 5, -1}};        // row block, first pass: hooks 0..5
+constexpr HookMap kMapRowD{{10, 11, 12, -1, 13, 14, 15, -1}};  // ... second pass: hooks 10..15 (6..9: twiddles)
+#ifndef CLFA_RES16_PIN_HOOKS
+#define CLFA_RES16_PIN_HOOKS 1
+#endif
+// a hook stays where it is written: without the fences hipcc lets the arithmetic drift around the asm
+// statements and the loads end up in clusters of four
+template <int G, class H> __device__ __forceinline__ void hook_at(const H &hook) {
+  if constexpr (G >= 0 && !std::is_same<H, HookNone>::value) {
+    if (CLFA_RES16_PIN_HOOKS) __builtin_amdgcn_sched_barrier(0);
+    hook(ic<G>());
+    if (CLFA_RES16_PIN_HOOKS) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// dft16 of fft_device.hpp with eight hook points
+template <bool FWD, class H, int P0, int P1, int P2, int P3, int P4, int P5, int P6, int P7>
+__device__ __forceinline__ void dft16_hp(cpx (&v)[16], const H &hook) {
+  bf4<FWD>(v[0], v[4], v[8], v[12]);
+  hook_at<P0>(hook);
+  bf4<FWD>(v[1], v[5], v[9], v[13]);
+  hook_at<P1>(hook);
+  bf4<FWD>(v[2], v[6], v[10], v[14]);
+  hook_at<P2>(hook);
+  bf4<FWD>(v[3], v[7], v[11], v[15]);
+  ctw2<FWD>(v[4 + 1], kC16, kS16, v[4 + 2], kC8, kC8);
+  hook_at<P3>(hook);
+  ctw2<FWD>(v[4 + 3], kS16, kC16, v[8 + 1], kC8, kC8);
+  ctw2<FWD>(v[8 + 3], -kC8, kC8, v[12 + 1], kS16, kC16);
+  hook_at<P4>(hook);
+  ctw2<FWD>(v[12 + 2], -kC8, kC8, v[12 + 3], -kC16, -kS16);
+  cpx x[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) x[t] = v[t];
+  bf4<FWD>(x[0], x[1], x[2], x[3]);
+  hook_at<P5>(hook);
+  bf4<FWD>(x[4], x[5], x[6], x[7]);
+  hook_at<P6>(hook);
+  bf4_rot2<FWD>(x[8], x[9], x[10], x[11]);
+  hook_at<P7>(hook);
+  bf4<FWD>(x[12], x[13], x[14], x[15]);
+#pragma unroll
+  for (int q0 = 0; q0 < 4; q0++)
+#pragma unroll
+    for (int q1 = 0; q1 < 4; q1++) v[q0 + 4 * q1] = x[4 * q0 + q1];
+}
+#define CLFA_DFT16_H(FWD, v, hook, M) \
+  dft16_hp<FWD, decltype(hook), M.p[0], M.p[1], M.p[2], M.p[3], M.p[4], M.p[5], M.p[6], M.p[7]>(v, hook)
 
 struct ResLane {
   int c, t;          // lane = c + 16 t
@@ -151,8 +369,10 @@ struct ResLane {
 
 // ---- phase 1: one column block ------------------------------------------------------------------
 // v: rows t + 16 e of column n2 = 16 cb + c (already loaded) -> o[e] = Z[t + 16 e][n2]
-template <bool FWD, int PROBE = 0> __device__ __forceinline__ void res_col_block(cpx (&v)[16], const ResLane &L, int cb, const cpx *s_tab, cpx *s_x) {
-  dft16<1, 16, FWD>(v, 0);
+template <bool FWD, int PROBE = 0, class H = HookNone>
+__device__ __forceinline__ void res_col_block(cpx (&v)[16], const ResLane &L, int cb, const cpx *s_tab, cpx *s_x,
+                                              const H &hook = H()) {
+  if constexpr (!(PROBE & kProbeNoMath)) CLFA_DFT16_H(FWD, v, hook, kMapColA);
   res_barrier<PROBE>();   // the previous block's readers are done with the exchange buffer
   {
     f4 *pw = reinterpret_cast<f4 *>(L.xa_w);
@@ -162,7 +382,25 @@ template <bool FWD, int PROBE = 0> __device__ __forceinline__ void res_col_block
   res_barrier<PROBE>();
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = L.xa_r[16 * e];
-  twiddled_dft16<FWD>(v, L.tw_row);
+  if constexpr (PROBE & kProbeNoMath) return;
+  // second pass: inputs times W_256^(t j) (row t of the table), then the butterflies
+  {
+    const f4 *pt = reinterpret_cast<const f4 *>(L.tw_row);
+    {
+      const f4 w = pt[0];
+      v[1] = cmulc<!FWD>(v[1], mk(w.z, w.w));
+    }
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+      const f4 w = pt[i];
+      cmulc2<!FWD>(v[2 * i], v[2 * i + 1], v[2 * i], mk(w.x, w.y), v[2 * i + 1], mk(w.z, w.w));
+      if (i == 1) hook_at<4>(hook);
+      if (i == 3) hook_at<5>(hook);
+      if (i == 5) hook_at<6>(hook);
+      if (i == 7) hook_at<7>(hook);
+    }
+  }
+  CLFA_DFT16_H(FWD, v, hook, kMapColB);
   // four-step twiddles W_N^(n2 (t + 16 e)) = b * s^e,  b = W_N^(n2 t),  s = W_4096^n2
   const int n2 = cb * 16 + L.c;
   const int m = n2 * L.t;   // < 4096
@@ -174,20 +412,30 @@ template <bool FWD, int PROBE = 0> __device__ __forceinline__ void res_col_block
   T[0] = b;
   cmulc2(T[1], T[2], b, s1, b, s2);
   cmulc2(T[3], U[0], T[1], s2, b, s8);
+  hook_at<12>(hook);
   cmulc2(U[1], U[2], T[1], s8, T[2], s8);
   U[3] = cmul(T[3], s8);
 #pragma unroll
-  for (int r = 0; r < 4; r++) cmulc2<!FWD>(v[r], v[r + 8], v[r], T[r], v[r + 8], U[r]);
+  for (int r = 0; r < 4; r++) {
+    cmulc2<!FWD>(v[r], v[r + 8], v[r], T[r], v[r + 8], U[r]);
+    if (r == 1) hook_at<13>(hook);
+  }
   cmulc2(T[0], T[1], T[0], s4, T[1], s4);
   cmulc2(T[2], T[3], T[2], s4, T[3], s4);
+  hook_at<14>(hook);
   cmulc2(U[0], U[1], T[0], s8, T[1], s8);
   cmulc2(U[2], U[3], T[2], s8, T[3], s8);
 #pragma unroll
-  for (int r = 0; r < 4; r++) cmulc2<!FWD>(v[r + 4], v[r + 12], v[r + 4], T[r], v[r + 12], U[r]);
+  for (int r = 0; r < 4; r++) {
+    cmulc2<!FWD>(v[r + 4], v[r + 12], v[r + 4], T[r], v[r + 12], U[r]);
+    if (r == 1) hook_at<15>(hook);
+  }
 }
 
 // o[e] -> keep[e][cb]
-template <int PROBE = 0>
+// LAST (column block 15): the slot's element goes straight to its landing register (the rest of that row
+// block is on its way there, HookSlot)
+template <int PROBE = 0, bool LAST = false>
 __device__ __forceinline__ void res_deposit(const cpx (&o)[16], const ResLane &L, int cb, f32x32 (&K)[kVgprBlk],
                                             __amdgpu_buffer_rsrc_t slot) {
   {
@@ -196,7 +444,8 @@ __device__ __forceinline__ void res_deposit(const cpx (&o)[16], const ResLane &L
     for (int e = 0; e < kLdsBlk; e++) ps[e * 16] = o[e];
   }
   // the one row block that does not fit the CU: [cb][lane] in the workgroup's 32 KiB slot (L2-resident)
-  if constexpr (!(PROBE & kProbeNoSlot))
+  if constexpr (LAST) res_stage_one15(o[kLdsBlk]);
+  else if constexpr (!(PROBE & kProbeNoSlot))
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o[kLdsBlk]), slot, L.slot_off, cb * 2048, 0);
 #pragma unroll
   for (int j = 0; j < kVgprBlk; j++) {
@@ -232,27 +481,11 @@ template <int RB> __device__ __forceinline__ void res_fetch_static(cpx (&v)[16],
     acc_fetch<RB - kAgprFirst>(v, std::make_integer_sequence<int, 16>());
   }
 }
-// (rb = 3, the global slot's block: `slot_v`, loaded at the start of phase 2)
-__device__ __forceinline__ void res_fetch(cpx (&v)[16], const ResLane &L, int rb, const f32x32 (&K)[kVgprBlk],
-                                          const cpx (&slot_v)[16]) {
-  switch (rb) {
-#define CLFA_C(r) case r: res_fetch_static<r>(v, L, K); break;
-    CLFA_C(0) CLFA_C(1) CLFA_C(2)
-    case kLdsBlk:
-#pragma unroll
-      for (int e = 0; e < 16; e++) v[e] = slot_v[e];
-      break;
-    CLFA_C(4) CLFA_C(5) CLFA_C(6) CLFA_C(7)
-    CLFA_C(8) CLFA_C(9) CLFA_C(10) CLFA_C(11) CLFA_C(12) CLFA_C(13) CLFA_C(14)
-#undef CLFA_C
-    default: res_fetch_static<15>(v, L, K); break;
-  }
-}
-
 // ---- phase 2: one row block ---------------------------------------------------------------------
 // v[e] = Z[16 rb + t][c + 16 e] -> X[16 rb + c + 256 (t + 16 e)] left in v[e] (lane = row c, k2 = t + 16 e)
-template <bool FWD, int PROBE = 0> __device__ __forceinline__ void res_row_block(cpx (&v)[16], const ResLane &L) {
-  dft16<1, 16, FWD>(v, 0);
+template <bool FWD, int PROBE = 0, class H = HookNone>
+__device__ __forceinline__ void res_row_block(cpx (&v)[16], const ResLane &L, const H &hook = H()) {
+  if constexpr (!(PROBE & kProbeNoMath)) CLFA_DFT16_H(FWD, v, hook, kMapRowC);
   res_barrier<PROBE>();
   {
     f4 *pw = reinterpret_cast<f4 *>(L.xb_w);
@@ -262,14 +495,68 @@ template <bool FWD, int PROBE = 0> __device__ __forceinline__ void res_row_block
   res_barrier<PROBE>();
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = L.xb_r[18 * e];
-  twiddled_dft16<FWD>(v, L.tw_row);
+  if constexpr (PROBE & kProbeNoMath) return;
+  {
+    const f4 *pt = reinterpret_cast<const f4 *>(L.tw_row);
+    {
+      const f4 w = pt[0];
+      v[1] = cmulc<!FWD>(v[1], mk(w.z, w.w));
+    }
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+      const f4 w = pt[i];
+      cmulc2<!FWD>(v[2 * i], v[2 * i + 1], v[2 * i], mk(w.x, w.y), v[2 * i + 1], mk(w.z, w.w));
+      if (i == 1) hook_at<6>(hook);
+      if (i == 3) hook_at<7>(hook);
+      if (i == 5) hook_at<8>(hook);
+      if (i == 7) hook_at<9>(hook);
+    }
+  }
+  CLFA_DFT16_H(FWD, v, hook, kMapRowD);
+}
+
+// phase 1, one column block: wait for its data (N younger asm loads), take it out of its landing zone
+// (ZC >= 0: AGPR columns ZC, ZC + 1; ZC < 0: v[224:255]), transform it with the loads of the block two
+// ahead riding along (-> AGPR columns NZ, NZ + 1, or the landing registers for NZ < 0; none if !LOAD)
+template <bool FWD, int PROBE, int ZC, int NZ, bool LOAD, int N = 16, bool LAST = false>
+__device__ __forceinline__ void res_phase1_block(cpx (&v)[16], const ResLane &L, const cpx *x, int cb, int rot,
+                                                 const int (&so)[16], f32x32 (&K)[kVgprBlk], __amdgpu_buffer_rsrc_t slot,
+                                                 const cpx *s_tab, cpx *s_x) {
+  if constexpr (!(PROBE & (kProbeNoLoad | kProbeNoWait))) res_wait_vm<N>();
+  if constexpr (ZC >= 0) acc_fetch_raw<ZC>(v, std::make_integer_sequence<int, 8>());
+  else res_land_fetch(v);
+  if constexpr (LOAD && !(PROBE & kProbeNoLoad)) {
+    const __amdgpu_buffer_rsrc_t r = res_rsrc(x + ((cb + 2 + rot) & 15) * 16);
+    if constexpr (NZ >= 0) res_col_block<FWD, PROBE>(v, L, cb, s_tab, s_x, HookAcc<NZ>{r, L.voff, so});
+    else res_col_block<FWD, PROBE>(v, L, cb, s_tab, s_x, HookLand{r, L.voff, so});
+  } else if constexpr (LAST && !(PROBE & kProbeNoSlot)) {
+    res_col_block<FWD, PROBE>(v, L, cb, s_tab, s_x, HookSlot{slot, L.slot_off, so});
+  } else {
+    res_col_block<FWD, PROBE>(v, L, cb, s_tab, s_x);
+  }
+  res_deposit<PROBE, LAST>(v, L, cb, K, slot);
 }
 
 }  // namespace
 
+// probe only: all workgroups meet (monotonic counter; bounded spin)
+__device__ __forceinline__ void res_probe_grid_sync(unsigned long long *dbg, unsigned &epoch) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned *cnt = reinterpret_cast<unsigned *>(dbg + 1024);
+    epoch += gridDim.x;
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; spin < 2000000; spin++) {
+      if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+}
+
 // slots: one 32 KiB slot per workgroup (the single row block that does not fit the CU)
 template <bool FWD, bool SCALE, int PROBE = 0>
-__global__ __launch_bounds__(256) void k_fft_res16(cpx *__restrict__ data, cpx *__restrict__ slots,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_fft_res16(cpx *__restrict__ data, cpx *__restrict__ slots,
                                                    const cpx *__restrict__ tabs_g, long batch,
                                                    unsigned long long *__restrict__ dbg = nullptr) {
   __shared__ __attribute__((aligned(16))) cpx s_tab[kTabSize];
@@ -282,76 +569,125 @@ __global__ __launch_bounds__(256) void k_fft_res16(cpx *__restrict__ data, cpx *
     if (SCALE && i >= kTabLo && i < kTabHi) w = cscale(w, 1.0f / (float)kN);   // exact: a power of two
     s_tab[i] = w;
   }
-  ResLane L;
-  L.c = tid & 15;
-  L.t = tid >> 4;
-  L.voff = L.t * 2048 + L.c * 8;
-  L.xa_w = s_x + L.c * kXA + 16 * L.t;
-  L.xa_r = s_x + L.c * kXA + L.t;
-  L.xb_w = s_x + L.t * kXB + 18 * L.c;
-  L.xb_r = s_x + L.c * kXB + L.t;
-  L.tw_row = s_tab + kTabTw + 16 * L.t;
-  L.spill = s_spill + tid * kSpillStride;
-  L.slot_off = tid * 8;
+  // The lane's addresses are recomputed from an opaque copy of the lane index wherever a block
+  // starts: as loop invariants they would cost ~13 VGPRs for the whole kernel, which hipcc then
+  // parks in AGPRs (this kernel's own)
+  auto lane = [&]() {
+    int l = tid;
+    asm volatile("" : "+v"(l));
+    ResLane L;
+    L.c = l & 15;
+    L.t = l >> 4;
+    L.voff = L.t * 2048 + L.c * 8;
+    L.xa_w = s_x + L.c * kXA + 16 * L.t;
+    L.xa_r = s_x + L.c * kXA + L.t;
+    L.xb_w = s_x + L.t * kXB + 18 * L.c;
+    L.xb_r = s_x + L.c * kXB + L.t;
+    L.tw_row = s_tab + kTabTw + 16 * L.t;
+    L.spill = s_spill + l * kSpillStride;
+    L.slot_off = l * 8;
+    return L;
+  };
+  const int rot = (PROBE & kProbeRotate) ? (int)(blockIdx.x & 15) : 0;   // probe only: 0 in the library
+  int so[16];   // row offsets e * 32 KiB of the asm loads, pinned in SGPRs (never rematerialised next to a load)
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    so[e] = e * 32768;
+    asm volatile("" : "+s"(so[e]));
+  }
   const __amdgpu_buffer_rsrc_t slot = res_rsrc(slots + (long)blockIdx.x * 4096);
   __syncthreads();
 
   f32x32 K[kVgprBlk];
 #pragma unroll
   for (int j = 0; j < kVgprBlk; j++) K[j] = 0.f;
-  cpx v[16], vn[16];
+  cpx v[16];
   long b = blockIdx.x;
   unsigned long long clk1 = 0, clk2 = 0;
-  res_load<PROBE>(v, res_rsrc(data + b * (long)kN), L.voff);
+  unsigned epoch = 0;   // probe only (the host zeroes the counter before the launch)
+  // blocks 0 and 1 of the first transform
+  if constexpr (!(PROBE & kProbeNoLoad)) {
+    const ResLane L0 = lane();
+    res_load_acc<kZone0>(data + b * (long)kN + (rot & 15) * 16, L0.voff);
+    res_load_land(data + b * (long)kN + ((1 + rot) & 15) * 16, L0.voff);
+  }
 #pragma unroll 1
   for (; b < batch; b += gridDim.x) {
     cpx *x = data + b * (long)kN;
     unsigned long long t0 = 0;
     if constexpr (PROBE & kProbeStamps) t0 = __builtin_amdgcn_s_memtime();
-    // ---- phase 1: column blocks two at a time (v and vn change roles), the next block's loads in flight
+    // ---- phase 1: four column blocks per round (landing zones Z0, v[224:255], Z1, v[224:255]); on entry
+    // block 0 is in (or on its way to) Z0 and block 1 on its way to the landing registers
 #pragma unroll 1
-    for (int cb = 0; cb < 14; cb += 2) {
-      res_load<PROBE>(vn, res_rsrc(x + (cb + 1) * 16), L.voff);
-      res_col_block<FWD, PROBE>(v, L, cb, s_tab, s_x);
-      res_deposit<PROBE>(v, L, cb, K, slot);
-      res_load<PROBE>(v, res_rsrc(x + (cb + 2) * 16), L.voff);
-      res_col_block<FWD, PROBE>(vn, L, cb + 1, s_tab, s_x);
-      res_deposit<PROBE>(vn, L, cb + 1, K, slot);
+    for (int cb = 0; cb < 12; cb += 4) {
+      res_phase1_block<FWD, PROBE, kZone0, kZone1, true>(v, lane(), x, cb, rot, so, K, slot, s_tab, s_x);
+      res_phase1_block<FWD, PROBE, -1, -1, true>(v, lane(), x, cb + 1, rot, so, K, slot, s_tab, s_x);
+      res_phase1_block<FWD, PROBE, kZone1, kZone0, true>(v, lane(), x, cb + 2, rot, so, K, slot, s_tab, s_x);
+      res_phase1_block<FWD, PROBE, -1, -1, true>(v, lane(), x, cb + 3, rot, so, K, slot, s_tab, s_x);
     }
-    res_load<PROBE>(vn, res_rsrc(x + 15 * 16), L.voff);
-    res_col_block<FWD, PROBE>(v, L, 14, s_tab, s_x);
-    res_deposit<PROBE>(v, L, 14, K, slot);
-    res_col_block<FWD, PROBE>(vn, L, 15, s_tab, s_x);
-    res_deposit<PROBE>(vn, L, 15, K, slot);
-    // ---- phase 2: row blocks; the slot's block comes back behind the first three (agent-scope
-    // loads: they bypass this CU's L1, which may still hold the previous transform's lines)
+    res_phase1_block<FWD, PROBE, kZone0, kZone1, true>(v, lane(), x, 12, rot, so, K, slot, s_tab, s_x);
+    res_phase1_block<FWD, PROBE, -1, -1, true>(v, lane(), x, 13, rot, so, K, slot, s_tab, s_x);
+    res_phase1_block<FWD, PROBE, kZone1, -1, false>(v, lane(), x, 14, rot, so, K, slot, s_tab, s_x);
+    res_phase1_block<FWD, PROBE, -1, -1, false, 0, true>(v, lane(), x, 15, rot, so, K, slot, s_tab, s_x);
     if constexpr (PROBE & kProbeStamps) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
       clk1 += t1 - t0;
       t0 = t1;
     }
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      if constexpr (PROBE & kProbeNoSlot) asm volatile("" : "+v"(vn[e]));
-      else vn[e] = __builtin_bit_cast(cpx, __builtin_amdgcn_raw_buffer_load_b64(slot, L.slot_off, e * 2048, 16));
+    if constexpr (PROBE & kProbeGridSync) {
+      res_probe_grid_sync(dbg, epoch);
+      t0 = __builtin_amdgcn_s_memtime();
     }
-#pragma unroll 1
-    for (int rb = 0; rb < 15; rb++) {
-      res_fetch(v, L, rb, K, vn);
-      res_row_block<FWD, PROBE>(v, L);
-      res_store<PROBE>(v, res_rsrc(x + rb * 16), L.voff);
-    }
-    // last row block: the next transform's first column block is loaded behind it (index clamped to
-    // the last transform so that the loads are straight-line code)
-    long bn = b + gridDim.x;
+    // ---- phase 2: row blocks in the order slot (its data are in the landing registers by now), AGPR
+    // (the accumulation file is then free for the next transform's block 0), VGPR, LDS.  A block's results
+    // are parked in the landing registers and stored while the next block is computed.
+    long bn = b + gridDim.x;   // next transform (clamped: its first loads are issued unconditionally)
     bn = bn < batch ? bn : batch - 1;
-    res_load<PROBE>(vn, res_rsrc(data + bn * (long)kN), L.voff);
-    res_fetch_static<15>(v, L, K);
-    res_row_block<FWD, PROBE>(v, L);
-    res_store<PROBE>(v, res_rsrc(x + 15 * 16), L.voff);
-#pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = vn[e];
+    const cpx *xn = data + bn * (long)kN;
+    {
+      const ResLane L = lane();
+      if constexpr (!(PROBE & kProbeNoSlot)) res_wait_vm<0>();
+      res_land_fetch(v);
+      res_row_block<FWD, PROBE>(v, L);
+      res_stage(v);
+    }
+    int rb_prev = kLdsBlk;
+#pragma unroll 1
+    for (int it = (PROBE & kProbePhase1Only) ? 14 : 1; it < 15; it++) {
+      const ResLane L = lane();
+      int rb;
+      switch (it) {
+#define CLFA_C(k, r) case k: res_fetch_static<r>(v, L, K); rb = r; break;
+        CLFA_C(1, 8) CLFA_C(2, 9) CLFA_C(3, 10) CLFA_C(4, 11) CLFA_C(5, 12) CLFA_C(6, 13) CLFA_C(7, 14) CLFA_C(8, 15)
+        CLFA_C(9, 4) CLFA_C(10, 5) CLFA_C(11, 6) CLFA_C(12, 7) CLFA_C(13, 0)
+#undef CLFA_C
+        default: res_fetch_static<1>(v, L, K); rb = 1; break;
+      }
+      if constexpr (!(PROBE & kProbeNoLoad)) {
+        if (it == 13) res_load_acc<kZone0>(xn + (rot & 15) * 16, L.voff);
+      }
+      if constexpr (!(PROBE & kProbeNoStore)) {
+        res_row_block<FWD, PROBE>(v, L, HookStore{res_rsrc(x + ((rb_prev + rot) & 15) * 16), L.voff, so});
+      } else {
+        res_row_block<FWD, PROBE>(v, L);
+      }
+      res_stage(v);
+      rb_prev = rb;
+    }
+    {
+      const ResLane L = lane();
+      res_fetch_static<2>(v, L, K);
+      if constexpr (!(PROBE & kProbeNoStore)) {
+        res_row_block<FWD, PROBE>(v, L, HookStore{res_rsrc(x + ((rb_prev + rot) & 15) * 16), L.voff, so});
+      } else {
+        res_row_block<FWD, PROBE>(v, L);
+      }
+      res_store<PROBE>(v, res_rsrc(x + ((2 + rot) & 15) * 16), L.voff);
+      // the next transform's block 1 -> landing registers (after this block's parked stores have been issued)
+      if constexpr (!(PROBE & kProbeNoLoad)) res_load_land(xn + ((1 + rot) & 15) * 16, L.voff);
+    }
     if constexpr (PROBE & kProbeStamps) clk2 += __builtin_amdgcn_s_memtime() - t0;
+    if constexpr (PROBE & kProbeGridSync) res_probe_grid_sync(dbg, epoch);
   }
   if constexpr (PROBE & kProbeStamps) {
     if (tid == 0) {

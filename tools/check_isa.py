@@ -1,20 +1,60 @@
 #!/usr/bin/env python3
 """Guards on the resident FFT kernel's code object (run on CPU; tests/test_abi_cpu.py calls it).
 
-The kernel manages the accumulation register file by hand (literal a[N] numbers in inline asm), so
-the compiler must not place anything of its own there: no v_accvgpr_* outside the asm blocks, no
-scratch memory, and the arch VGPR count must stay within 256.
+The kernel (opencl_fft_amd/csrc/fft_resident.hip) does two things hipcc cannot check:
+  * it manages the accumulation register file by hand (literal a[N] in inline asm), so the compiler
+    must not place anything of its own there: no v_accvgpr_* outside the asm blocks, no scratch;
+  * it issues global loads from inline asm (hipcc neither counts nor waits for them) into AGPRs and
+    into v[224:255], which amdgpu_num_vgpr(224) keeps out of the register allocator's hands: no
+    compiler-generated instruction may name those registers (with compiler-allocated destinations
+    hipcc was seen copying them ahead of the kernel's own s_waitcnt, i.e. before the data had landed).
 
 usage: check_isa.py file.s   (hipcc -save-temps of fft_resident.hip)
 """
 import re
 import sys
 
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+RESERVED_FIRST = 224   # v[224:255]: landing registers of asm-issued loads (kernel built with amdgpu_num_vgpr(224))
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def audit_reserved(body):
+    """no instruction outside the kernel's own asm statements may name a reserved VGPR"""
+    problems = []
+    inasm = False
+    for ln in body.split("\n"):
+        s = ln.strip()
+        if "ASMSTART" in s:
+            inasm = True
+            continue
+        if "ASMEND" in s:
+            inasm = False
+            continue
+        if inasm or not s or s.startswith((";", ".")):
+            continue
+        code = s.split(";")[0]
+        hit = [r for r in regs_of(code) if r >= RESERVED_FIRST]
+        if hit:
+            problems.append("compiler instruction touches reserved v%s: %s" % (sorted(hit), code.strip()))
+    return problems
+
 
 def check(path):
     s = open(path).read()
     problems = []
+    found = 0
     for m in re.finditer(r"^(_ZN4clfa11k_fft_res16[A-Za-z0-9_]+):", s, re.M):
+        found += 1
         name = m.group(1)
         body = s[m.end():]
         body = body[:body.index(".Lfunc_end")]
@@ -31,6 +71,10 @@ def check(path):
             problems.append("%s: %d compiler-generated AGPR moves" % (name, stray))
         if re.search(r"\bscratch_(load|store)", body):
             problems.append("%s: scratch memory accesses" % name)
+        for p in audit_reserved(body):
+            problems.append("%s: %s" % (name, p))
+    if not found:
+        problems.append("no k_fft_res16 kernel in %s" % path)
     return problems
 
 

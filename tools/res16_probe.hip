@@ -24,9 +24,13 @@ template <int PROBE> static void run(const char *name, cpx *data, cpx *slots, cp
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const int warm = 10, reps = 40;
-  for (int i = 0; i < warm; i++) hipLaunchKernelGGL((k_fft_res16<true, false, PROBE>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, dbg);
+  auto launch = [&] {
+    if (PROBE & 512) CK(hipMemsetAsync(dbg + 1024, 0, 8, 0));
+    hipLaunchKernelGGL((k_fft_res16<true, false, PROBE>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, dbg);
+  };
+  for (int i = 0; i < warm; i++) launch();
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_fft_res16<true, false, PROBE>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, dbg);
+  for (int i = 0; i < reps; i++) launch();
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   CK(hipGetLastError());
@@ -49,6 +53,30 @@ template <int PROBE> static void run(const char *name, cpx *data, cpx *slots, cp
   printf("\n");
 }
 
+// the same work as `parts` launches of batch / parts transforms each: kernel boundaries keep the
+// workgroups' read and write phases aligned chip-wide
+static void run_split(cpx *data, cpx *slots, cpx *tabs, long batch, int cus, int parts) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int warm = 5, reps = 20;
+  const long per = batch / parts;
+  auto once = [&] {
+    for (int p = 0; p < parts; p++)
+      hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data + p * per * 65536, slots, tabs, per, (unsigned long long *)nullptr);
+  };
+  for (int i = 0; i < warm; i++) once();
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; i++) once();
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("%2d launches of %4ld transforms          %8.3f ms  %6.2f TB/s alg\n", parts, per, ms, batch * 65536.0 * 16 / ms * 1e-9);
+}
+
 int main() {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -59,7 +87,8 @@ int main() {
   CK(hipMalloc(&data, batch * 65536 * 8));
   CK(hipMalloc(&slots, (size_t)cus * 32768));
   CK(hipMalloc(&tabs, 1792 * 8));
-  CK(hipMalloc(&dbg, cus * 16));
+  CK(hipMalloc(&dbg, 16384));
+  CK(hipMemset(dbg, 0, 16384));
   CK(hipMemset(data, 0, batch * 65536 * 8));
   std::vector<cpx> t(1792);
   for (int i = 0; i < 1792; i++) t[i] = mk((float)cos(i * 0.001), (float)sin(i * 0.001));   // unit-modulus stand-ins: timing only
@@ -69,10 +98,17 @@ int main() {
   run<16>("full + stamps", data, slots, tabs, dbg, batch, cus);
   run<1 | 16>("no loads", data, slots, tabs, dbg, batch, cus);
   run<2 | 16>("no stores", data, slots, tabs, dbg, batch, cus);
-  run<8 | 16>("no slot traffic", data, slots, tabs, dbg, batch, cus);
   run<1 | 2 | 8 | 16>("no global traffic at all", data, slots, tabs, dbg, batch, cus);
-  run<1 | 2 | 8 | 4 | 16>("no global traffic, no barriers", data, slots, tabs, dbg, batch, cus);
-  run<4 | 16>("no barriers", data, slots, tabs, dbg, batch, cus);
+  run<32 | 16>("loads never waited for", data, slots, tabs, dbg, batch, cus);
+  run<64 | 16>("no arithmetic", data, slots, tabs, dbg, batch, cus);
+  run<64 | 4 | 16>("no arithmetic, no barriers", data, slots, tabs, dbg, batch, cus);
+  run<128 | 2 | 16>("phase 1 only (+2 row blocks), no stores", data, slots, tabs, dbg, batch, cus);
+  run<128 | 2 | 64 | 16>("phase 1 only, no stores, no arithmetic", data, slots, tabs, dbg, batch, cus);
+  run<256 | 16>("rotated column-block order", data, slots, tabs, dbg, batch, cus);
+  run<256 | 2 | 16>("rotated, no stores", data, slots, tabs, dbg, batch, cus);
+  run<256 | 1 | 16>("rotated, no loads", data, slots, tabs, dbg, batch, cus);
+  run<512 | 16>("grid barrier at phase boundaries", data, slots, tabs, dbg, batch, cus);
   run<0>("full (again)", data, slots, tabs, dbg, batch, cus);
+  for (int parts : {1, 2, 4, 8, 16}) run_split(data, slots, tabs, batch, cus, parts);
   return 0;
 }
