@@ -52,6 +52,8 @@ template <bool REAL> struct FftOp : csnd::Plugin<1, 3> {
   uint32_t np2;
 
   int init() {
+    delete plan;   // reinit without deinit (the struct starts zeroed: Csound runs no constructor)
+    plan = nullptr;
     csnd::Vector<MYFLT> &in = inargs.vector_data<MYFLT>(0);
     csnd::Vector<MYFLT> &out = outargs.vector_data<MYFLT>(0);
     out.init(csound, in.len(), this);
@@ -94,11 +96,14 @@ template <bool REAL> struct FftOp : csnd::Plugin<1, 3> {
 // Both buffer `parts` samples, run one block through the device and emit it one block later
 // (latency = one partition, as the reference); parts == 1 selects direct convolution with
 // vsize = ksmps.
+// No in-class initialisers: Csound zero-allocates opcode structs and runs no constructor, so a null
+// pointer here always comes from that zeroed memory.  init() may run again on the same struct (reinit)
+// without an intervening deinit(): it releases whatever a previous init() left.
 struct ConvBase {
-  cl_conv::Clpconv *pconv = nullptr;
-  cl_conv::Cldconv *dconv = nullptr;
-  int parts = 0, cnt = 0;
-  bool direct = false;
+  cl_conv::Clpconv *pconv;
+  cl_conv::Cldconv *dconv;
+  int parts, cnt;
+  bool direct;
   void release() {
     delete pconv;
     delete dconv;
@@ -111,6 +116,7 @@ struct Conv : csnd::Plugin<1, 6>, ConvBase {
   csnd::AuxMem<float> bufin, bufout;
 
   int init() {
+    release();   // reinit without deinit must not leak the previous device objects
     cl_device_id id;
     if (!pick_device(csound, (int)inargs[3], id)) return csound->init_error("failed to find a device!\n");
     csnd::Table ir;
@@ -176,6 +182,7 @@ struct TVConv : csnd::Plugin<1, 7>, ConvBase {
   csnd::AuxMem<float> bufin1, bufin2, bufout;
 
   int init() {
+    release();   // see Conv::init
     cl_device_id id;
     if (!pick_device(csound, (int)inargs[6], id)) return csound->init_error("failed to find a device!\n");
     parts = (int)inargs[4];

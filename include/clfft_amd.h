@@ -22,6 +22,10 @@
  * "_dev" entry points that work in place on device-resident buffers on a
  * caller-supplied hipStream_t (passed as void*; NULL is the HIP default stream, as
  * everywhere in HIP).  Work is ordered by that stream only; nothing blocks.
+ * A plan / convolution object owns ONE device workspace, so it may have work in flight on one
+ * stream at a time: when a call names another stream than the object's previous call, the library
+ * first waits (on the host) for that previous stream.  Every entry point leaves the calling
+ * thread's current HIP device as it found it.
  */
 #ifndef CLFFT_AMD_H
 #define CLFFT_AMD_H
@@ -100,12 +104,6 @@ CLFA_API int clfa_fft_exec_dev(clfa_fft *plan, void *data, long batch, void *str
 CLFA_API size_t clfa_fft_workspace_bytes(const clfa_fft *plan);
 /* name of the HIP kernel that does the work for this plan (for profiles) */
 CLFA_API const char *clfa_fft_kernel_name(const clfa_fft *plan);
-/* waits for `stream` and returns CLFA_SUCCESS, or CLFA_OUT_OF_RESOURCES if the large-N kernel's
- * bounded dependency waits ever timed out during the plan's last launch (results then invalid) */
-CLFA_API int clfa_fft_sync_check(clfa_fft *plan, void *stream);
-/* tuning: variant id of the n = 2^14..2^16 kernel (0 = default, 1..9 = older shapes kept for A/B);
- * returns CLFA_INVALID_VALUE if unknown */
-CLFA_API int clfa_fft_set_variant(clfa_fft *plan, int variant);
 
 /* the reference's `reorder` kernel as a stand-alone op (cl_fft.cpp:24-27):
  * out[b*n + k] = in[b*n + bitrev(k)], exact gather of complex64, out != in */
@@ -124,7 +122,9 @@ CLFA_API int clfa_pconv_wp(const clfa_pconv *pc);
 CLFA_API int clfa_pconv_wp2(const clfa_pconv *pc);
 /* Clpconv::push_ir(ir), cl_conv.cpp:353-388: ir = channels x (nparts*pts) floats */
 CLFA_API int clfa_pconv_push_ir(clfa_pconv *pc, const float *ir);
-CLFA_API int clfa_pconv_push_ir_dev(clfa_pconv *pc, const void *ir, void *stream);
+/* device-resident form: channel c's response starts at ir + c * channel_stride floats
+ * (channel_stride >= nparts*pts; a (channels, cvs) tensor passes cvs), nparts*pts floats are read of each */
+CLFA_API int clfa_pconv_push_ir_dev(clfa_pconv *pc, const void *ir, long channel_stride, void *stream);
 /* Clpconv::convolution(out, in), cl_conv.cpp:393-458: channels x pts floats each */
 CLFA_API int clfa_pconv_convolution(clfa_pconv *pc, float *out, const float *in);
 /* Clpconv::convolution(out, in1, in2), cl_conv.cpp:460-548 (time-varying) */

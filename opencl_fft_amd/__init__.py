@@ -119,13 +119,6 @@ class _Plan:
     def kernel_name(self):
         return lib().clfa_fft_kernel_name(self._h).decode()
 
-    def set_variant(self, v):
-        return lib().clfa_fft_set_variant(self._h, v)
-
-    def sync_check(self, stream=None):
-        """wait for `stream`; non-zero if the large-N kernel's bounded waits ever timed out"""
-        return lib().clfa_fft_sync_check(self._h, stream)
-
     def exec_device(self, data, batch, stream=None):
         """in place on device memory, asynchronous on `stream` (Clcfft::fft(), cl_fft.cpp:138-151)"""
         p, stream = _ptr_stream(data, stream)
@@ -248,8 +241,18 @@ class Clpconv:
         return lib().clfa_pconv_convolution_tv(self._h, output.ctypes.data, a.ctypes.data, b.ctypes.data)
 
     def push_ir_device(self, ir, stream=None):
+        """ir: device tensor (channels, >= nparts*pts) of float32, rows contiguous; a (channels, cvs)
+        tensor with cvs not a multiple of pts is fine (the remainder of every row is ignored, like the
+        reference's floor(cvs / pts), cl_conv.cpp:143)"""
+        need = self.nparts * self.pts
+        shape, strides = tuple(ir.shape), tuple(ir.stride())
+        if ir.dim() == 1:
+            shape, strides = (1,) + shape, (shape[0],) + strides
+        if (len(shape) != 2 or shape[0] != self.channels or shape[1] < need or strides[1] != 1
+                or (shape[0] > 1 and strides[0] < need) or str(ir.dtype) != "torch.float32"):
+            return -30   # CL_INVALID_VALUE
         p, stream = _ptr_stream(ir, stream)
-        return lib().clfa_pconv_push_ir_dev(self._h, p, stream)
+        return lib().clfa_pconv_push_ir_dev(self._h, p, strides[0], stream)
 
     def process_device(self, out, in1, in2=None, stream=None):
         po, stream = _ptr_stream(out, stream)

@@ -30,8 +30,6 @@ SYMBOLS = [
     ("clfa_fft_exec_dev", C.c_int, [_vp, _vp, C.c_long, _vp]),
     ("clfa_fft_workspace_bytes", C.c_size_t, [_vp]),
     ("clfa_fft_kernel_name", C.c_char_p, [_vp]),
-    ("clfa_fft_set_variant", C.c_int, [_vp, C.c_int]),
-    ("clfa_fft_sync_check", C.c_int, [_vp, _vp]),
     ("clfa_reorder_dev", C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_long, _vp]),
     ("clfa_pconv_create", C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int]),
     ("clfa_pconv_destroy", None, [_vp]),
@@ -40,7 +38,7 @@ SYMBOLS = [
     ("clfa_pconv_wp", C.c_int, [_vp]),
     ("clfa_pconv_wp2", C.c_int, [_vp]),
     ("clfa_pconv_push_ir", C.c_int, [_vp, _vp]),
-    ("clfa_pconv_push_ir_dev", C.c_int, [_vp, _vp, _vp]),
+    ("clfa_pconv_push_ir_dev", C.c_int, [_vp, _vp, C.c_long, _vp]),
     ("clfa_pconv_convolution", C.c_int, [_vp, _vp, _vp]),
     ("clfa_pconv_convolution_tv", C.c_int, [_vp, _vp, _vp, _vp]),
     ("clfa_pconv_process_dev", C.c_int, [_vp, _vp, _vp, _vp, _vp]),

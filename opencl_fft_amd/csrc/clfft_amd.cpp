@@ -48,6 +48,42 @@ int map_hip(hipError_t e) {
     }                                   \
   } while (0)
 
+// current-device guard: every entry point works on its object's device and leaves the caller's
+// current device as it found it
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t enter(int device) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev == device) return hipSuccess;
+    e = hipSetDevice(device);
+    switched = e == hipSuccess;
+    return e;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+#define ENTER_DEVICE(dev) \
+  DeviceGuard _guard;     \
+  HIP_TRY(_guard.enter(dev))
+
+// An object owns one device workspace: work on a second stream has to wait for the first.  Switching
+// streams is rare (the reference has one queue per object), so the wait is a host-side synchronise
+// at the switch instead of an event per launch.
+struct StreamOrder {
+  hipStream_t last = nullptr;
+  bool any = false;
+  hipError_t use(hipStream_t s) {
+    hipError_t e = hipSuccess;
+    if (any && s != last) e = hipStreamSynchronize(last);
+    last = s;
+    any = true;
+    return e;
+  }
+};
+
 int ilog2(int n) {
   int l = 0;
   while ((1 << l) < n) l++;
@@ -196,10 +232,10 @@ struct clfa_fft {
   int logn = 0;
   int size = 0;          // user-visible size (n, or real points for Clrfft)
   int err = 0;           // Clcfft::cl_err
-  int variant = 0;
   char log[2048];
   hipStream_t stream = nullptr;
-  DevBuf half, w2, four, scratch, stage, ctl, res16;
+  DevBuf half, w2, four, scratch, stage, res16;
+  StreamOrder order;
   HostBuf zstage;        // zero-copy staging of small host transforms
   FftTables tabs;
   // n > 65536 (extension): n = N1 x N2; `tabs` then belongs to the N2-point row transform
@@ -219,6 +255,8 @@ struct clfa_pconv {
   DevBuf in1, in2, out, ir;          // staging for the host entry points
   HostBuf zin1, zin2, zout;          // ... zero-copy staging for small blocks
   DevBuf four, scratch, work;        // partitions above the LDS sizes: large-N tables, scratch, work frames
+  StreamOrder order;
+  bool fused = false;                // one launch per block (resolved at creation)
   FftTables big;
 };
 
@@ -228,6 +266,7 @@ struct clfa_dconv {
   int err = 0;
   hipStream_t stream = nullptr;
   DevBuf del, coefs, out;
+  StreamOrder order;
 };
 
 extern "C" {
@@ -338,7 +377,7 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
   p->logn = ilog2(n);
   int e = device_info(device, p->di);
   if (e) return e;
-  HIP_TRY(hipSetDevice(device));
+  ENTER_DEVICE(device);
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   std::vector<cpx> h;
   int rown = n, rowlog = p->logn;   // the transform the LDS / four-step tables are for
@@ -381,12 +420,11 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     if (rowlog == 16) {
       fill_res16_tables(all);
       if ((e = upload(p->res16, all.data(), sizeof(cpx) * all.size()))) return e;
+      p->tabs.res16 = (const cpx *)p->res16.p;
     }
-    size_t sbytes = (size_t)fourstep_grid(rowlog, p->variant, p->di) * rown * sizeof(cpx);
-    if (p->variant == kVariantCoop) sbytes = coop_scratch_bytes(rowlog);
+    size_t sbytes = (size_t)fourstep_grid(p->di) * rown * sizeof(cpx);
     DevBuf &ws = p->logn > kMaxLog ? p->scratch2 : p->scratch;
     if ((e = ws.ensure(sbytes))) return e;
-    if ((e = p->ctl.ensure(coop_ctl_bytes() > coop2_ctl_bytes() ? coop_ctl_bytes() : coop2_ctl_bytes()))) return e;
   }
   if (real) {
     fill_w2(h, n, fwd ? -1.f : 1.f);
@@ -422,8 +460,9 @@ int clfa_rfft_create(clfa_fft **plan, int device, int size, int forward) {
 
 void clfa_fft_destroy(clfa_fft *p) {
   if (!p) return;
+  DeviceGuard guard;
+  (void)guard.enter(p->di.device);
   if (p->stream) {
-    (void)hipSetDevice(p->di.device);
     (void)hipStreamSynchronize(p->stream);
     (void)hipStreamDestroy(p->stream);
   }
@@ -432,7 +471,6 @@ void clfa_fft_destroy(clfa_fft *p) {
   p->four.release();
   p->scratch.release();
   p->stage.release();
-  p->ctl.release();
   p->res16.release();
   p->zstage.release();
   p->bigtabs.release();
@@ -447,39 +485,7 @@ size_t clfa_fft_workspace_bytes(const clfa_fft *p) { return p ? p->scratch.bytes
 const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
   if (p->logn > kMaxLog) return "k_big_cols";
-  return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn, p->fwd, p->variant);
-}
-
-int clfa_fft_set_variant(clfa_fft *p, int variant) {
-  if (!p || variant < 0 || variant > kVariantMax) return CLFA_INVALID_VALUE;
-  if (p->err) return p->err;
-  if (p->logn > kMaxLog) return variant == 0 ? CLFA_SUCCESS : CLFA_INVALID_VALUE;
-  p->variant = variant;
-  if (p->logn > kLdsMaxLog) {
-    HIP_TRY(hipSetDevice(p->di.device));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    size_t sbytes = (size_t)fourstep_grid(p->logn, variant, p->di) * p->n * sizeof(cpx);
-    if (variant == kVariantCoop || variant == kVariantCoop2) sbytes = coop_scratch_bytes(p->logn);
-    int e = p->scratch.ensure(sbytes);
-    if (e) return e;
-  }
-  return CLFA_SUCCESS;
-}
-
-int clfa_fft_sync_check(clfa_fft *p, void *stream) {
-  if (!p) return CLFA_INVALID_VALUE;
-  if (p->err) return p->err;
-  HIP_TRY(hipSetDevice(p->di.device));
-  hipStream_t s = (hipStream_t)stream;
-  unsigned err = 0;
-  if (p->logn > kMaxLog) {
-    HIP_TRY(hipStreamSynchronize(s));
-    return CLFA_SUCCESS;
-  }
-  if (p->logn > kLdsMaxLog && p->variant == kVariantCoop && p->ctl.p) HIP_TRY(coop_read_error(p->ctl.p, &err, s));
-  if (p->logn > kLdsMaxLog && p->variant == kVariantCoop2 && p->ctl.p) HIP_TRY(coop2_read_error(p->ctl.p, &err, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  return err ? CLFA_OUT_OF_RESOURCES : CLFA_SUCCESS;
+  return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
 }
 
 int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
@@ -487,8 +493,9 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   if (p->err) return p->err;
   if (!data || batch < 0) return CLFA_INVALID_VALUE;
   if (batch == 0) return CLFA_SUCCESS;
-  HIP_TRY(hipSetDevice(p->di.device));
+  ENTER_DEVICE(p->di.device);
   hipStream_t s = (hipStream_t)stream;  // NULL is the HIP default stream
+  HIP_TRY(p->order.use(s));
   cpx *d = (cpx *)data;
   const bool scale = p->fwd;  // cl_fft.cpp:39-40: forward plans divide by N, inverse plans do not
   if (p->logn <= kLdsMaxLog) {
@@ -504,14 +511,9 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
       HIP_TRY(launch_fft_big(p->big, p->fwd, scale, d + b0 * (long)p->n, (cpx *)p->scratch.p, (cpx *)p->scratch2.p,
                              (const cpx *)p->bigtabs.p, p->tabs, nb, p->di, s));
     }
-  } else if (p->variant == kVariantCoop)
-    HIP_TRY(launch_fft_coop(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));
-  else if (p->variant == kVariantCoop2)
-    HIP_TRY(launch_fft_coop2(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->ctl.p, p->tabs, batch, p->di, s));
-  else if (p->logn == 16 && p->variant == 0 && batch * 4 > p->di.num_cus && !getenv("CLFA_NO_RES16"))
-    HIP_TRY(launch_fft_res16(p->fwd, scale, d, (cpx *)p->scratch.p, (const cpx *)p->res16.p, batch, p->di, s));
-  else
-    HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, p->variant, d, (cpx *)p->scratch.p, p->tabs, batch, p->di, s));
+  } else {
+    HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->tabs, batch, p->di, s));
+  }
   if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, p->n, batch, s));
   return CLFA_SUCCESS;
 }
@@ -534,7 +536,7 @@ int clfa_cfft_transform(clfa_fft *p, float *c, long batch) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!c || batch < 0 || p->real) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(p->di.device));
+  ENTER_DEVICE(p->di.device);
   const size_t per = sizeof(cpx) * (size_t)p->n;
   if (batch > 0 && per * (size_t)batch <= kZeroCopyMax) {
     int e = p->zstage.ensure(per * batch);
@@ -563,7 +565,7 @@ int clfa_rfft_transform(clfa_fft *p, float *c, float *r, long batch) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!c || !r || batch < 0 || !p->real) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(p->di.device));
+  ENTER_DEVICE(p->di.device);
   const size_t per = sizeof(cpx) * (size_t)p->n;  // size floats == M complex
   if (batch > 0 && per * (size_t)batch <= kZeroCopyMax) {
     int e = p->zstage.ensure(per * batch);
@@ -592,7 +594,7 @@ int clfa_rfft_transform(clfa_fft *p, float *c, float *r, long batch) {
 
 int clfa_reorder_dev(int device, void *out, const void *in, int n, long batch, void *stream) {
   if (!out || !in || out == in || !is_pow2(n) || n < 2 || batch < 0) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(device));
+  ENTER_DEVICE(device);
   HIP_TRY(launch_reorder((cpx *)out, (const cpx *)in, ilog2(n), batch, (hipStream_t)stream));
   return CLFA_SUCCESS;
 }
@@ -614,7 +616,8 @@ static int pconv_setup(clfa_pconv *p, int device, int cvs, int pts, int channels
   p->wp2 = p->g.nparts - 1;        // cl_conv.cpp:144
   int e = device_info(device, p->di);
   if (e) return e;
-  HIP_TRY(hipSetDevice(device));
+  p->fused = pconv_fused_ok(p->g, p->di) && !getenv("CLFA_PCONV_NO_FUSE");   // tuning switch, read once
+  ENTER_DEVICE(device);
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   std::vector<cpx> h;
   fill_twiddle(h, pts / 2, pts, 1, -1.f);
@@ -629,7 +632,7 @@ static int pconv_setup(clfa_pconv *p, int device, int cvs, int pts, int channels
     fill_fourstep_tables(all, p->g.logb);
     if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
     p->big.four = (const cpx *)p->four.p;
-    if ((e = p->scratch.ensure((size_t)fourstep_grid(p->g.logb, 0, p->di) * n * sizeof(cpx)))) return e;
+    if ((e = p->scratch.ensure((size_t)fourstep_grid(p->di) * n * sizeof(cpx)))) return e;
     if ((e = p->work.ensure(sizeof(cpx) * (size_t)channels * n))) return e;
   }
   const size_t ring = sizeof(cpx) * (size_t)channels * p->g.nparts * pts;
@@ -657,8 +660,9 @@ int clfa_pconv_create(clfa_pconv **pc, int device, int cvs, int pts, int channel
 
 void clfa_pconv_destroy(clfa_pconv *p) {
   if (!p) return;
+  DeviceGuard guard;
+  (void)guard.enter(p->di.device);
   if (p->stream) {
-    (void)hipSetDevice(p->di.device);
     (void)hipStreamSynchronize(p->stream);
     (void)hipStreamDestroy(p->stream);
   }
@@ -689,7 +693,7 @@ static int pconv_forward(clfa_pconv *p, const float *in, long in_stride, cpx *ri
   const int bins = p->g.bins, ch = p->g.channels;
   cpx *work = (cpx *)p->work.p;
   HIP_TRY(launch_pconv_pad(in, in_stride, work, bins, ch, s));
-  HIP_TRY(launch_fft_4step(p->g.logb, true, false, 0, work, (cpx *)p->scratch.p, p->big, ch, p->di, s));
+  HIP_TRY(launch_fft_4step(p->g.logb, true, false, work, (cpx *)p->scratch.p, p->big, ch, p->di, s));
   HIP_TRY(launch_r2c_pack(work, (const cpx *)p->w2f.p, bins, ch, s));
   HIP_TRY(hipMemcpy2DAsync(ring + (size_t)frame * bins, sizeof(cpx) * (size_t)p->g.nparts * bins, work,
                            sizeof(cpx) * (size_t)bins, sizeof(cpx) * (size_t)bins, ch, hipMemcpyDeviceToDevice, s));
@@ -706,18 +710,19 @@ static int pconv_inverse(clfa_pconv *p, float *out, hipStream_t s) {
   const int bins = p->g.bins, ch = p->g.channels;
   cpx *acc = (cpx *)p->acc.p;
   HIP_TRY(launch_c2r_unpack(acc, (const cpx *)p->w2i.p, bins, ch, s));
-  HIP_TRY(launch_fft_4step(p->g.logb, false, false, 0, acc, (cpx *)p->scratch.p, p->big, ch, p->di, s));
+  HIP_TRY(launch_fft_4step(p->g.logb, false, false, acc, (cpx *)p->scratch.p, p->big, ch, p->di, s));
   HIP_TRY(launch_pconv_olap((const float *)acc, (float *)p->tail.p, out, bins, ch, s));
   return CLFA_SUCCESS;
 }
 
-int clfa_pconv_push_ir_dev(clfa_pconv *p, const void *ir, void *stream) {
+int clfa_pconv_push_ir_dev(clfa_pconv *p, const void *ir, long channel_stride, void *stream) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
-  if (!ir) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(p->di.device));
+  if (!ir || channel_stride < (long)p->g.nparts * p->pts) return CLFA_INVALID_VALUE;
+  ENTER_DEVICE(p->di.device);
   hipStream_t s = (hipStream_t)stream;
-  const long stride = (long)p->g.nparts * p->pts;
+  HIP_TRY(p->order.use(s));
+  const long stride = channel_stride;
   // cl_conv.cpp:358-386: partition i -> frame wp2, wp2 counts down from nparts-1
   for (int i = 0; i < p->g.nparts; i++) {
     int e = pconv_forward(p, (const float *)ir + (long)i * p->pts, stride, (cpx *)p->ringB.p, p->wp2, s);
@@ -731,12 +736,12 @@ int clfa_pconv_push_ir(clfa_pconv *p, const float *ir) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!ir) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(p->di.device));
+  ENTER_DEVICE(p->di.device);
   const size_t bytes = sizeof(float) * (size_t)p->g.channels * p->g.nparts * p->pts;
   int e = p->ir.ensure(bytes);
   if (e) return e;
   HIP_TRY(hipMemcpyAsync(p->ir.p, ir, bytes, hipMemcpyHostToDevice, p->stream));
-  if ((e = clfa_pconv_push_ir_dev(p, p->ir.p, p->stream))) return e;
+  if ((e = clfa_pconv_push_ir_dev(p, p->ir.p, (long)p->g.nparts * p->pts, p->stream))) return e;
   HIP_TRY(hipStreamSynchronize(p->stream));
   return CLFA_SUCCESS;
 }
@@ -745,10 +750,11 @@ int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!out || !in1) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(p->di.device));
+  ENTER_DEVICE(p->di.device);
   hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(p->order.use(s));
   int e;
-  if (pconv_fused_ok(p->g, p->di) && !getenv("CLFA_PCONV_NO_FUSE")) {
+  if (p->fused) {
     // whole block in one launch; ring indices advance exactly as below
     const int frame1 = p->wp, frame2 = p->wp2;
     p->wp = p->wp != p->g.nparts - 1 ? p->wp + 1 : 0;
@@ -780,7 +786,7 @@ static int pconv_host(clfa_pconv *p, float *out, const float *in1, const float *
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!out || !in1) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(p->di.device));
+  ENTER_DEVICE(p->di.device);
   const size_t blk = sizeof(float) * (size_t)p->g.channels * p->pts;
   int e;
   if (blk <= kZeroCopyMax) {
@@ -827,7 +833,7 @@ int clfa_dconv_create(clfa_dconv **dc, int device, int irsize, int vsize) {
     if (irsize < 1 || vsize < 1 || (long)irsize * vsize > 0x7fffffffL) return CLFA_INVALID_VALUE;
     int e = device_info(device, d->di);
     if (e) return e;
-    HIP_TRY(hipSetDevice(device));
+    ENTER_DEVICE(device);
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     const size_t ring = sizeof(float) * ((size_t)irsize + vsize);
     if ((e = d->del.ensure(ring)) || (e = d->coefs.ensure(ring)) || (e = d->out.ensure(sizeof(float) * vsize)))
@@ -844,8 +850,9 @@ int clfa_dconv_create(clfa_dconv **dc, int device, int irsize, int vsize) {
 
 void clfa_dconv_destroy(clfa_dconv *d) {
   if (!d) return;
+  DeviceGuard guard;
+  (void)guard.enter(d->di.device);
   if (d->stream) {
-    (void)hipSetDevice(d->di.device);
     (void)hipStreamSynchronize(d->stream);
     (void)hipStreamDestroy(d->stream);
   }
@@ -861,7 +868,7 @@ int clfa_dconv_push_ir(clfa_dconv *d, const float *ir) {
   if (!d) return CLFA_INVALID_VALUE;
   if (d->err) return d->err;
   if (!ir) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(d->di.device));
+  ENTER_DEVICE(d->di.device);
   HIP_TRY(hipMemcpyAsync(d->coefs.p, ir, sizeof(float) * d->irsize, hipMemcpyHostToDevice, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   return CLFA_SUCCESS;
@@ -882,7 +889,7 @@ int clfa_dconv_convolution(clfa_dconv *d, float *out, const float *in) {
   if (!d) return CLFA_INVALID_VALUE;
   if (d->err) return d->err;
   if (!out || !in) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(d->di.device));
+  ENTER_DEVICE(d->di.device);
   int e = ring_write(d, d->del, in);
   if (e) return e;
   d->wp = (d->wp + d->vsize) % (d->irsize + d->vsize);   // cl_dconv.cpp:124
@@ -897,7 +904,7 @@ int clfa_dconv_convolution_tv(clfa_dconv *d, float *out, const float *in1, const
   if (!d) return CLFA_INVALID_VALUE;
   if (d->err) return d->err;
   if (!out || !in1 || !in2) return CLFA_INVALID_VALUE;
-  HIP_TRY(hipSetDevice(d->di.device));
+  ENTER_DEVICE(d->di.device);
   int e = ring_write(d, d->coefs, in2);   // cl_dconv.cpp:134-147
   if (e) return e;
   return clfa_dconv_convolution(d, out, in1);

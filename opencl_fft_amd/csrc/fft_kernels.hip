@@ -15,9 +15,6 @@
 //                conv / iconv / reorder kernels.
 #include <cstdlib>
 
-#ifndef CLFA_4STEP_OPAQUE
-#define CLFA_4STEP_OPAQUE 1
-#endif
 
 #include "fft_wg.hpp"
 
@@ -634,15 +631,16 @@ __device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__
   four_body2<LOGN, FWD, SCALE, SM>(v, dst, rb, l, tab2, sx, read_done);
 }
 
-// ROWS (with PF): the first row block of every slice — rows k1 < KL = NSLICE * R2, 1/8 of the
+// The first row block of every slice — rows k1 < KL = NSLICE * R2, 1/8 of the
 // intermediate for n = 65536 — stays in LDS between the phases instead of going through the scratch
-template <int LOGN, bool FWD, bool SCALE, int NSLICE, bool NT, bool PF = false, bool ROWS = false>
-__global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ data, cpx *__restrict__ scratch,
+template <int LOGN, bool FWD, bool SCALE>
+__global__ __launch_bounds__(512) void k_fft_4step(cpx *__restrict__ data, cpx *__restrict__ scratch,
                                                            const cpx *__restrict__ tabs_g, long batch) {
   using G = FourGeom<LOGN>;
-  static_assert(!ROWS || PF, "LDS-resident rows are wired into the prefetching form only");
-  constexpr bool OPQ = CLFA_4STEP_OPAQUE;
-  constexpr int KL = ROWS ? NSLICE * G::R2 : 0;
+  constexpr int NSLICE = 2;        // two 256-lane slices per workgroup
+  constexpr bool NT = true;        // non-temporal input loads / output stores
+  constexpr bool ROWS = true, PF = true;
+  constexpr int KL = NSLICE * G::R2;
   // ... and the next RRB row blocks of every slice in registers (16 VGPRs per block; the 512-lane
   // workgroup has 256 per lane): 5 of the remaining 7 for n = 65536, all of them for 32768 (3) and
   // 16384 (1), whose scratch is then never touched
@@ -657,7 +655,7 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
   __shared__ cpx s_full[PF ? G::N1 + G::N2 : 1];
   const int tid = threadIdx.x;
   for (int i = tid; i < G::TABS; i += 256 * NSLICE) s_tabs[i] = tabs_g[i];
-  const cpx *tab1 = s_tabs, *tab2 = s_tabs + G::N1 / 2, *tlo = tab2 + G::N2 / 2, *thi = tlo + G::LO;
+  const cpx *tlo = s_tabs + G::N1 / 2 + G::N2 / 2, *thi = tlo + G::LO;
   if constexpr (PF) {
     for (int i = tid; i < G::N1 + G::N2; i += 256 * NSLICE) {
       const bool second = i >= G::N1;
@@ -681,23 +679,7 @@ __global__ __launch_bounds__(256 * NSLICE) void k_fft_4step(cpx *__restrict__ da
 #pragma unroll 1
   for (long b = blockIdx.x; b < batch; b += gridDim.x) {
     cpx *x = data + b * (long)G::N;
-    if constexpr (!PF) {
-#pragma unroll 1
-      for (int cb = slice; cb < G::NCB; cb += NSLICE) {
-        int lo_ = l;   // opaque per iteration: keeps hipcc from hoisting (and spilling) every LDS / global offset
-        if (OPQ) asm volatile("" : "+v"(lo_));
-        four_phase1<LOGN, FWD, NT ? 1 : 0>(x, mid, cb, lo_, tab1, tlo, thi, sx);
-      }
-      // the workgroup re-reads what it has just stored: workgroup-scope release/acquire
-      __syncthreads();
-#pragma unroll 1
-      for (int rb = slice; rb < G::NRB; rb += NSLICE) {
-        int lo_ = l;
-        if (OPQ) asm volatile("" : "+v"(lo_));
-        four_phase2<LOGN, FWD, SCALE, NT ? 1 : 0>(mid, x, rb, lo_, tab2, sx);
-      }
-      __syncthreads();
-    } else {
+    {
       // software-prefetched form: the next block's loads fly behind the current block's passes.
       // The last block of each phase is peeled so that every prefetch is straight-line code
       // (counted s_waitcnt, see k_fft_lds), and consumed at the end of the iteration.
@@ -838,46 +820,12 @@ __global__ __launch_bounds__(256) void k_fft_4step_rows(cpx *__restrict__ data, 
   four_phase2<LOGN, FWD, SCALE, 0>(scratch + b * (long)G::N, data + b * (long)G::N, blockIdx.x, tid, tab2, s_x);
 }
 
-struct FourVariant {
-  int nslice;
-  bool nt;
-  int wg_per_cu;
-  bool pf;   // software prefetch of the next column / row block
-  bool rows = false;   // first row block of every slice stays in LDS
-};
-static FourVariant four_variant(int variant) {
-  // {slices of 256 lanes per workgroup, non-temporal streaming, workgroups per CU, software prefetch}.
-  // Measured on MI355X, N = 65536 x 4096, interleaved in one process (tools/ab_variants.py): the
-  // prefetching shapes (0, 1) run 1.32-1.37 ms, the others 1.40-1.56 ms; the process-to-process
-  // spread is ~5 %.  7 and 8 are the XCD-cooperative kernels (kVariantCoop, kVariantCoop2).
-  switch (variant) {
-    case 1: return {2, true, 2, true};
-    case 2: return {1, true, 2, true};
-    case 3: return {2, true, 2, false};
-    case 4: return {1, true, 2, false};
-    case 5: return {4, true, 1, false};
-    case 6: return {2, false, 2, false};
-    case 9: return {2, true, 1, true};   // the default's shape without the LDS-resident rows
-    default: return {2, true, 1, true, true};  // 0: software prefetch, one workgroup per CU, 128 MiB of scratch, LDS rows
-  }
-}
-
-int fourstep_grid(int logn, int variant, const DeviceInfo &di) {
-  (void)logn;
-  // tuning knob for experiments: CLFA_4STEP_GRID=<workgroups>
-  if (const char *e = getenv("CLFA_4STEP_GRID")) {
-    int g = atoi(e);
-    if (g > 0) return g;
-  }
-  FourVariant v = four_variant(variant);
-  return di.num_cus * v.wg_per_cu;
-}
+int fourstep_grid(const DeviceInfo &di) { return di.num_cus; }   // one 512-lane workgroup per CU
 
 template <int LOGN, bool FWD, bool SCALE>
-static hipError_t launch_4step_v(int variant, cpx *data, cpx *scratch, const FftTables &t, long batch,
-                                 const DeviceInfo &di, hipStream_t s) {
-  FourVariant v = four_variant(variant);
-  int grid = fourstep_grid(LOGN, variant, di);
+static hipError_t launch_4step_v(cpx *data, cpx *scratch, const FftTables &t, long batch, const DeviceInfo &di,
+                                 hipStream_t s) {
+  int grid = fourstep_grid(di);
   if (batch * 4 <= grid && batch <= 65535) {
     // few transforms: spread each over its column / row blocks (scratch holds `grid` transforms)
     using G = FourGeom<LOGN>;
@@ -886,526 +834,38 @@ static hipError_t launch_4step_v(int variant, cpx *data, cpx *scratch, const Fft
                        t.four);
     return hipGetLastError();
   }
-  if (batch < grid) grid = (int)batch;
-  if (v.rows) {
-    hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE, 2, true, true, true>), dim3(grid), dim3(512), 0, s, data, scratch,
-                       t.four, batch);
+  if constexpr (LOGN == 16) {
+    // n = 65536: the resident kernel (fft_resident.hip); `scratch` provides its per-workgroup slots
+    return launch_fft_res16(FWD, SCALE, data, scratch, t.res16, batch, di, s);
+  } else {
+    if (batch < grid) grid = (int)batch;
+    hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE>), dim3(grid), dim3(512), 0, s, data, scratch, t.four, batch);
     return hipGetLastError();
   }
-#define CLFA_V(NS, NT, PF)                                                                                  \
-  if (v.nslice == NS && v.nt == NT && v.pf == PF) {                                                         \
-    hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE, NS, NT, PF>), dim3(grid), dim3(256 * NS), 0, s, data, \
-                       scratch, t.four, batch);                                                             \
-    return hipGetLastError();                                                                               \
-  }
-  CLFA_V(2, true, true) CLFA_V(1, true, true) CLFA_V(2, true, false) CLFA_V(1, true, false) CLFA_V(4, true, false)
-  CLFA_V(2, false, false)
-#undef CLFA_V
+}
+
+template <int LOGN>
+static hipError_t launch_4step_n(bool fwd, bool scale, cpx *data, cpx *scratch, const FftTables &t, long batch,
+                                 const DeviceInfo &di, hipStream_t s) {
+  if (fwd && scale) return launch_4step_v<LOGN, true, true>(data, scratch, t, batch, di, s);
+  if (fwd && !scale) return launch_4step_v<LOGN, true, false>(data, scratch, t, batch, di, s);
+  if (!fwd && !scale) return launch_4step_v<LOGN, false, false>(data, scratch, t, batch, di, s);
   return hipErrorInvalidValue;
 }
 
-template <int LOGN>
-static hipError_t launch_4step_n(bool fwd, bool scale, int variant, cpx *data, cpx *scratch, const FftTables &t,
-                                 long batch, const DeviceInfo &di, hipStream_t s) {
-  if (fwd && scale) return launch_4step_v<LOGN, true, true>(variant, data, scratch, t, batch, di, s);
-  if (fwd && !scale) return launch_4step_v<LOGN, true, false>(variant, data, scratch, t, batch, di, s);
-  if (!fwd && !scale) return launch_4step_v<LOGN, false, false>(variant, data, scratch, t, batch, di, s);
-  return hipErrorInvalidValue;
-}
-
-hipError_t launch_fft_4step(int logn, bool fwd, bool scale, int variant, cpx *data, cpx *scratch,
-                            const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
+hipError_t launch_fft_4step(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, const FftTables &t, long batch,
+                            const DeviceInfo &di, hipStream_t s) {
   if (batch <= 0) return hipSuccess;
   switch (logn) {
-    case 14: return launch_4step_n<14>(fwd, scale, variant, data, scratch, t, batch, di, s);
-    case 15: return launch_4step_n<15>(fwd, scale, variant, data, scratch, t, batch, di, s);
-    case 16: return launch_4step_n<16>(fwd, scale, variant, data, scratch, t, batch, di, s);
+    case 14: return launch_4step_n<14>(fwd, scale, data, scratch, t, batch, di, s);
+    case 15: return launch_4step_n<15>(fwd, scale, data, scratch, t, batch, di, s);
+    case 16: return launch_4step_n<16>(fwd, scale, data, scratch, t, batch, di, s);
     default: return hipErrorInvalidValue;
   }
 }
 
-const char *name_fft_4step(int, bool, int) { return "k_fft_4step"; }
+const char *name_fft_4step(int logn) { return logn == 16 ? "k_fft_res16" : "k_fft_4step"; }
 
-
-// ---------------------------------------------------------------------------------
-// XCD-cooperative four-step FFT (variants 7 and 8; measured slower than the simple kernel, kept selectable)
-// ---------------------------------------------------------------------------------
-// Measured on MI355X (profiles/membench_r01.txt): a per-workgroup 512 KiB scratch costs a
-// full extra pass (3.6 TB/s algorithmic at best), but scratch that stays hot in the XCD's
-// 4 MiB L2 is free (5.2 TB/s, the copy rate) when the streamed input/output use
-// non-temporal accesses.  So the 256-lane workgroups of one XCD share a few scratch slots
-// and pull tasks — one column block (phase 1) or one row block (phase 2) of a transform —
-// from that XCD's queue in an order that keeps ~3-6 transforms live per XCD:
-//     P1(0) .. P1(LAG-1)  P1(LAG) P2(0)  P1(LAG+1) P2(1) ...   (groups of NCB = NRB tasks)
-// so P2(i) is queued 2*LAG+1 groups after P1(i): far enough that its inputs are normally
-// complete when it is dequeued, near enough that the live scratch stays in the L2.
-// A phase-2 task waits until all column blocks of its transform are stored, a phase-1
-// task until the previous user of its slot has been read.  A task waits only for tasks
-// that precede it in the queue, so the earliest unfinished task can always run: no
-// deadlock whatever the grid, residency or dispatch order.  Nothing relies on
-// workgroup -> XCD placement: the XCD is read from HW_REG_XCC_ID and every queue,
-// counter and scratch slot is private to the XCD that reads that id; counters are
-// agent-scope atomics; scratch is written with plain stores (they stay in the L2),
-// drained with s_waitcnt vmcnt(0) before the counter add, and read with sc1 loads.
-constexpr int kCoopMaxSlots = 16;
-constexpr unsigned kCoopNone = 0xFFFFFFFFu;
-constexpr unsigned kCoopSpinLimit = 1u << 20;
-
-// one record per scratch slot, read with a single pair of 8-byte loads per task.  Every
-// hot word sits on its own 128-byte line: atomics and polls to one line serialise at the
-// memory side (~11 ns each, MI355X_MICROARCH.md "fanin"/"dequeue").
-struct alignas(128) CoopSlot {
-  unsigned c1;   // finished phase-1 tasks on this slot (monotonic over the launch)
-  unsigned c2;   // phase-2 tasks that have finished READING this slot
-  unsigned tag;  // local transform index + 1 of the current owner
-  unsigned xf;   // its global transform index + 1
-};
-struct alignas(128) CoopWord {
-  unsigned v;
-};
-struct alignas(256) CoopXcd {
-  CoopWord head;    // task queue head
-  CoopWord draws;   // owner tasks that have drawn their global transform index (in queue order)
-  CoopWord endinv;  // 0xFFFFFFFF - (first local index without a transform); 0 = not known yet
-  CoopSlot slot[kCoopMaxSlots];
-};
-struct CoopCtl {
-  CoopXcd x[8];
-  CoopWord next_transform;
-  CoopWord error;
-};
-size_t coop_ctl_bytes() { return sizeof(CoopCtl); }
-
-// queue group g -> (phase, local transform index)
-__device__ __forceinline__ void coop_decode(unsigned g, unsigned lag, bool &p1, unsigned &i) {
-  if (g < lag) {
-    p1 = true;
-    i = g;
-  } else {
-    const unsigned h = g - lag;
-    p1 = !(h & 1u);
-    i = p1 ? lag + h / 2 : h / 2;
-  }
-}
-
-// Per-XCD control words are only ever touched by workgroups that read the same XCC_ID, i.e.
-// by clients of ONE L2.  Updates are read-modify-writes at workgroup scope: no sc1 bit, so
-// they execute in that L2 (a few hundred ns) instead of at the memory side (1-2 us).
-// Polls are sc1 loads: they bypass the vector L1 and are served by the same L2.  (A
-// `fetch_add(p, 0)` poll is folded by the compiler into an sc0 load that hits stale L1
-// lines — seen in the ISA and on hardware — so polls are written as agent-scope atomic loads.)
-#define CLFA_XCD_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
-__device__ __forceinline__ unsigned xcd_read(unsigned *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned xcd_add(unsigned *p, unsigned v) {
-  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
-}
-__device__ __forceinline__ void xcd_write(unsigned *p, unsigned v) {
-  (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
-}
-__device__ __forceinline__ CoopSlot coop_load_slot(CoopSlot *r) {
-  const unsigned long long a = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->c1), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long b = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&r->tag), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-  CoopSlot v;
-  v.c1 = (unsigned)a;
-  v.c2 = (unsigned)(a >> 32);
-  v.tag = (unsigned)b;
-  v.xf = (unsigned)(b >> 32);
-  return v;
-}
-
-template <int LOGN, bool FWD, bool SCALE, int SM = 1>
-__global__ __launch_bounds__(256, 3) void k_fft_coop(cpx *__restrict__ data, cpx *__restrict__ scratch,
-                                                     const cpx *__restrict__ tabs_g, long batch, CoopCtl *ctl,
-                                                     int nslots, int lag) {
-  using G = FourGeom<LOGN>;
-  static_assert(G::NCB == G::NRB, "task groups of both phases have the same size");
-  constexpr unsigned TPG = G::NCB;
-  // LDS tables: [lo | hi | (half N1 unless it is a prefix of hi)].  hi = W_HI^k is also the
-  // half table of every inner length that equals HI, which keeps the block under 40 KiB.
-  constexpr bool A1 = (G::N1 == G::HI), A2 = (G::N2 == G::HI);
-  static_assert(A2, "the row length equals the high twiddle table length for n = 2^14..2^16");
-  constexpr int CTABS = G::LO + G::HI + (A1 ? 0 : G::N1 / 2);
-  __shared__ cpx s_tabs[CTABS];
-  __shared__ cpx s_x[G::SL];
-  __shared__ unsigned s_q, s_xf;
-  const int tid = threadIdx.x;
-  {
-    const cpx *g_lo = tabs_g + G::N1 / 2 + G::N2 / 2;
-    for (int i = tid; i < G::LO + G::HI; i += 256) s_tabs[i] = g_lo[i];
-    if constexpr (!A1)
-      for (int i = tid; i < G::N1 / 2; i += 256) s_tabs[G::LO + G::HI + i] = tabs_g[i];
-  }
-  const cpx *tlo = s_tabs, *thi = s_tabs + G::LO;
-  const cpx *tab2 = thi, *tab1 = A1 ? thi : s_tabs + G::LO + G::HI;
-  const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;  // hwreg(HW_REG_XCC_ID, 0, 4)
-  CoopXcd *c = &ctl->x[xcc];
-  cpx *sbase = scratch + (long)xcc * nslots * G::N;
-
-  unsigned *pend = nullptr;  // lane 0: phase-1 completion counter still to be signalled
-
-  for (;;) {
-    // every wave drains the stores of its previous task; only then may its completion be
-    // signalled — and it must be signalled BEFORE this workgroup waits on anything, because
-    // the task it is about to resolve may depend on that very completion
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      if (pend) (void)xcd_add(pend, 1u);
-      pend = nullptr;
-      // ---- draw and resolve the next task --------------------------------------
-      // (drawing it earlier, during the previous task, would hide this round trip but
-      // doubles the queue window each workgroup occupies; measured 2x slower)
-      const unsigned q = xcd_add(&c->head.v, 1u);
-      const unsigned g = q / TPG, idx = q % TPG;
-      bool p1;
-      unsigned i;
-      coop_decode(g, (unsigned)lag, p1, i);
-      const unsigned slot = i % nslots, use = i / nslots;
-      CoopSlot *rec = &c->slot[slot];
-      unsigned xf = kCoopNone, n = 0;
-      bool known_end = i >= 0xFFFFFFFFu - xcd_read(&c->endinv.v);
-      if (known_end) {
-        // past the end of this XCD's share of the batch: nothing to do, nothing to wait for
-      } else if (p1 && idx == 0) {
-        // owner task of local transform i.  Global indices are drawn in queue order per XCD
-        // (ticket `draws`), so "the first local index that got none" is well defined.
-        while (xcd_read(&c->draws.v) != i) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++n > kCoopSpinLimit) {
-            __hip_atomic_store(&ctl->error.v, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-        const unsigned gi = __hip_atomic_fetch_add(&ctl->next_transform.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((long)gi >= batch)  // max of the complement = smallest local index that got none
-          __hip_atomic_fetch_max(&c->endinv.v, 0xFFFFFFFFu - i, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
-        xcd_write(&c->draws.v, i + 1);
-        if ((long)gi < batch) {
-          // wait until the slot's previous user has been read, then publish
-          while (use > 0 && coop_load_slot(rec).c2 < TPG * use) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++n > kCoopSpinLimit) {
-              __hip_atomic_store(&ctl->error.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              break;
-            }
-          }
-          xf = gi + 1;
-          (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&rec->tag),
-                                      ((unsigned long long)xf << 32) | (unsigned long long)(i + 1), __ATOMIC_RELAXED,
-                                      CLFA_XCD_SCOPE);
-        }
-      } else {
-        for (;;) {
-          const CoopSlot v = coop_load_slot(rec);
-          if (v.tag == i + 1 && (p1 || v.c1 >= TPG * (use + 1))) {
-            xf = v.xf;
-            break;
-          }
-          if (i >= 0xFFFFFFFFu - xcd_read(&c->endinv.v)) break;
-          __builtin_amdgcn_s_sleep(1);
-          if (++n > kCoopSpinLimit) {  // never hang the GPU: flag the launch and drop the task
-            __hip_atomic_store(&ctl->error.v, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
-      s_q = q;
-      s_xf = xf;
-    }
-    __syncthreads();
-    const unsigned q = s_q, xf = s_xf;
-    const unsigned g = q / TPG, idx = q % TPG;
-    bool p1;
-    unsigned i;
-    coop_decode(g, (unsigned)lag, p1, i);
-    CoopSlot *rec = &c->slot[i % nslots];
-    if (xf == kCoopNone) {
-      if (p1) continue;  // past the end: phase-2 tasks of earlier transforms still follow in the queue
-      break;
-    }
-    cpx *x = data + (long)(xf - 1) * G::N;
-    cpx *mid = sbase + (long)(i % nslots) * G::N;
-    if (p1) {
-      four_phase1<LOGN, FWD, SM>(x, mid, (int)idx, tid, tab1, tlo, thi, s_x);
-      if (tid == 0) pend = &rec->c1;  // signalled once every wave has drained its stores
-    } else {
-      four_phase2<LOGN, FWD, SCALE, SM, true>(mid, x, (int)idx, tid, tab2, s_x, &rec->c2);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// readiness-driven cooperative kernel (variant 8)
-// ---------------------------------------------------------------------------------
-// Same per-XCD structures as k_fft_coop, different scheduling: instead of one queue in a
-// fixed order, each XCD keeps
-//   p1_claim   phase-1 tasks claimed so far (transform = claim / TPG, column block = claim % TPG)
-//   ready[]    local transforms whose phase 1 is complete, in completion order (ready_tail entries)
-//   p2_claim   phase-2 tasks claimed so far (entry = claim / TPG of the ready list)
-// A workgroup first tries to claim a phase-2 task (only if one is READY: compare-and-swap on
-// p2_claim against ready_tail), else a phase-1 task (only if the slot of that transform is FREE),
-// else sleeps and retries.  A claimed task never waits for anything but short publication
-// windows of another running workgroup, so no workgroup ever holds a ticket it cannot run:
-// no deadlock for any grid size, residency or placement.  With S slots the steady state is
-// S/2 transforms in phase 1 and S/2 in phase 2 per XCD; live scratch = S x n x 8 bytes.
-constexpr int kCoopReadyRing = 64;
-struct alignas(256) Coop2Xcd {
-  CoopWord p1_claim, p2_claim, ready_tail, draws, endinv, p2_done;
-  CoopSlot slot[kCoopMaxSlots];
-  struct alignas(128) { unsigned long long v; } ready[kCoopReadyRing];  // (entry + 1) << 32 | local transform index
-};
-struct Coop2Ctl {
-  Coop2Xcd x[8];
-  CoopWord next_transform;
-  CoopWord error;
-};
-size_t coop2_ctl_bytes() { return sizeof(Coop2Ctl); }
-
-__device__ __forceinline__ bool xcd_cas(unsigned *p, unsigned expected, unsigned desired) {
-  return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
-}
-
-template <int LOGN, bool FWD, bool SCALE, int SM>
-__global__ __launch_bounds__(256, 3) void k_fft_coop2(cpx *__restrict__ data, cpx *__restrict__ scratch,
-                                                      const cpx *__restrict__ tabs_g, long batch, Coop2Ctl *ctl,
-                                                      int nslots) {
-  using G = FourGeom<LOGN>;
-  static_assert(G::NCB == G::NRB, "task groups of both phases have the same size");
-  constexpr unsigned TPG = G::NCB;
-  constexpr bool A1 = (G::N1 == G::HI), A2 = (G::N2 == G::HI);
-  static_assert(A2, "the row length equals the high twiddle table length for n = 2^14..2^16");
-  constexpr int CTABS = G::LO + G::HI + (A1 ? 0 : G::N1 / 2);
-  __shared__ cpx s_tabs[CTABS];
-  __shared__ cpx s_x[G::SL];
-  __shared__ unsigned s_kind, s_i, s_idx, s_xf;   // kind: 0 exit, 1 phase 1, 2 phase 2, 3 nothing to do yet
-  const int tid = threadIdx.x;
-  {
-    const cpx *g_lo = tabs_g + G::N1 / 2 + G::N2 / 2;
-    for (int i = tid; i < G::LO + G::HI; i += 256) s_tabs[i] = g_lo[i];
-    if constexpr (!A1)
-      for (int i = tid; i < G::N1 / 2; i += 256) s_tabs[G::LO + G::HI + i] = tabs_g[i];
-  }
-  const cpx *tlo = s_tabs, *thi = s_tabs + G::LO;
-  const cpx *tab2 = thi, *tab1 = A1 ? thi : s_tabs + G::LO + G::HI;
-  const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;  // hwreg(HW_REG_XCC_ID, 0, 4)
-  Coop2Xcd *c = &ctl->x[xcc];
-  cpx *sbase = scratch + (long)xcc * nslots * G::N;
-  unsigned *pend = nullptr;   // lane 0: slot record whose phase-1 completion is still to be signalled
-  unsigned pend_i = 0;
-  unsigned idle = 0;
-  // lane 0 holds at most one ticket of each kind (fetch_add claims: no retries, no contention).
-  // It runs whichever is runnable, phase 2 first; a ticket that is not runnable yet is kept while
-  // the workgroup does the other kind of work, so the smallest outstanding ticket of either
-  // kind always has a holder that can (eventually) run it: no deadlock.
-  unsigned p1t = kCoopNone, p2t = kCoopNone;
-
-  for (;;) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains the stores of its previous task
-    __syncthreads();
-    if (tid == 0) {
-      if (pend) {
-        // signal the completed phase-1 task; the 16th completion makes the transform READY
-        CoopSlot *rec = reinterpret_cast<CoopSlot *>(pend);
-        const unsigned use = pend_i / nslots;
-        const unsigned old = xcd_add(&rec->c1, 1u);
-        if (old + 1 == TPG * (use + 1)) {
-          const unsigned pos = xcd_add(&c->ready_tail.v, 1u);
-          (void)__hip_atomic_exchange(&c->ready[pos % kCoopReadyRing].v,
-                                      ((unsigned long long)(pos + 1) << 32) | pend_i, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
-        }
-        pend = nullptr;
-      }
-      unsigned kind = 3, ti = 0, tidx = 0, xf = kCoopNone;
-      if (p2t == kCoopNone) p2t = xcd_add(&c->p2_claim.v, 1u);
-      const unsigned rt = xcd_read(&c->ready_tail.v);
-      if (p2t / TPG < rt) {
-        // ---- my phase-2 ticket is READY ----------------------------------------------
-        const unsigned entry = p2t / TPG;
-        unsigned long long rv;
-        unsigned n = 0;
-        while ((unsigned)((rv = __hip_atomic_load(&c->ready[entry % kCoopReadyRing].v, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT)) >> 32) != entry + 1) {
-          __builtin_amdgcn_s_sleep(1);   // the pusher is between its tail increment and its store
-          if (++n > kCoopSpinLimit) { __hip_atomic_store(&ctl->error.v, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-        ti = (unsigned)rv;
-        tidx = p2t % TPG;
-        xf = coop_load_slot(&c->slot[ti % nslots]).xf;
-        kind = 2;
-        p2t = kCoopNone;
-      } else {
-        // ---- else my phase-1 ticket, if its transform's slot is usable -------------------
-        if (p1t == kCoopNone) p1t = xcd_add(&c->p1_claim.v, 1u);
-        const unsigned i = p1t / TPG, idx = p1t % TPG;
-        const unsigned endi = 0xFFFFFFFFu - xcd_read(&c->endinv.v);
-        if (i >= endi) {
-          // this XCD has no transform i; leave once my phase-2 ticket is past the last entry too
-          if (p2t / TPG >= endi) kind = 0;
-        } else {
-          CoopSlot *rec = &c->slot[i % nslots];
-          const unsigned use = i / nslots;
-          const CoopSlot v = coop_load_slot(rec);
-          if (idx == 0) {
-            // owner: previous user of the slot fully read, and it is my turn to draw a global index
-            if ((use == 0 || v.c2 >= TPG * use) && xcd_read(&c->draws.v) == i) {
-              const unsigned gi = __hip_atomic_fetch_add(&ctl->next_transform.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if ((long)gi >= batch) {
-                (void)__hip_atomic_fetch_max(&c->endinv.v, 0xFFFFFFFFu - i, __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
-              } else {
-                xf = gi + 1;
-                (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&rec->tag),
-                                            ((unsigned long long)xf << 32) | (unsigned long long)(i + 1),
-                                            __ATOMIC_RELAXED, CLFA_XCD_SCOPE);
-                ti = i;
-                tidx = 0;
-                kind = 1;
-              }
-              xcd_write(&c->draws.v, i + 1);
-              p1t = kCoopNone;
-            }
-          } else if (v.tag == i + 1) {   // the owner has published this transform
-            xf = v.xf;
-            ti = i;
-            tidx = idx;
-            kind = 1;
-            p1t = kCoopNone;
-          }
-        }
-      }
-      if (kind == 3) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++idle > kCoopSpinLimit) {   // never hang the GPU
-          __hip_atomic_store(&ctl->error.v, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          kind = 0;
-        }
-      } else {
-        idle = 0;
-      }
-      s_kind = kind;
-      s_i = ti;
-      s_idx = tidx;
-      s_xf = xf;
-    }
-    __syncthreads();
-    const unsigned kind = s_kind, i = s_i, idx = s_idx, xf = s_xf;
-    if (kind == 0) break;
-    if (kind == 3) continue;
-    CoopSlot *rec = &c->slot[i % nslots];
-    cpx *x = data + (long)(xf - 1) * G::N;
-    cpx *mid = sbase + (long)(i % nslots) * G::N;
-    if (kind == 1) {
-      four_phase1<LOGN, FWD, SM>(x, mid, (int)idx, tid, tab1, tlo, thi, s_x);
-      if (tid == 0) {
-        pend = &rec->c1;
-        pend_i = i;
-      }
-    } else {
-      four_phase2<LOGN, FWD, SCALE, SM, true>(mid, x, (int)idx, tid, tab2, s_x, &rec->c2);
-    }
-  }
-}
-
-template <int LOGN>
-static hipError_t launch_coop2_n(bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
-                                 long batch, const DeviceInfo &di, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(ctl, 0, sizeof(Coop2Ctl), s);
-  if (e != hipSuccess) return e;
-  int grid = di.num_cus * 2;
-  if (const char *g = getenv("CLFA_COOP_GRID")) {
-    int v = atoi(g);
-    if (v > 0) grid = v;
-  }
-  int ns = 4;
-  if (const char *e2 = getenv("CLFA_COOP_SLOTS")) {
-    int v = atoi(e2);
-    if (v >= 2 && v <= kCoopMaxSlots) ns = v;
-  }
-  int sm = 2;
-  if (const char *m = getenv("CLFA_COOP_STREAM")) sm = atoi(m);
-  Coop2Ctl *c = (Coop2Ctl *)ctl;
-#define CLFA_COOP2(F, S, M) hipLaunchKernelGGL((k_fft_coop2<LOGN, F, S, M>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns)
-  if (sm == 2) {
-    if (fwd && scale) CLFA_COOP2(true, true, 2); else if (fwd) CLFA_COOP2(true, false, 2); else CLFA_COOP2(false, false, 2);
-  } else {
-    if (fwd && scale) CLFA_COOP2(true, true, 1); else if (fwd) CLFA_COOP2(true, false, 1); else CLFA_COOP2(false, false, 1);
-  }
-#undef CLFA_COOP2
-  return hipGetLastError();
-}
-
-hipError_t launch_fft_coop2(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
-                            long batch, const DeviceInfo &di, hipStream_t s) {
-  if (batch <= 0) return hipSuccess;
-  switch (logn) {
-    case 14: return launch_coop2_n<14>(fwd, scale, data, scratch, ctl, t, batch, di, s);
-    case 15: return launch_coop2_n<15>(fwd, scale, data, scratch, ctl, t, batch, di, s);
-    case 16: return launch_coop2_n<16>(fwd, scale, data, scratch, ctl, t, batch, di, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-hipError_t coop2_read_error(const void *ctl, unsigned *err, hipStream_t s) {
-  return hipMemcpyAsync(err, &((const Coop2Ctl *)ctl)->error.v, sizeof(unsigned), hipMemcpyDeviceToHost, s);
-}
-
-int coop_slots() {
-  if (const char *e = getenv("CLFA_COOP_SLOTS")) {
-    int v = atoi(e);
-    if (v >= 2 && v <= kCoopMaxSlots) return v;
-  }
-  return 6;
-}
-size_t coop_scratch_bytes(int logn) { return (size_t)8 * kCoopMaxSlots * sizeof(cpx) << logn; }
-
-template <int LOGN>
-static hipError_t launch_coop_n(bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
-                                long batch, const DeviceInfo &di, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(ctl, 0, sizeof(CoopCtl), s);
-  if (e != hipSuccess) return e;
-  int grid = di.num_cus * 4;
-  if (const char *g = getenv("CLFA_COOP_GRID")) {
-    int v = atoi(g);
-    if (v > 0) grid = v;
-  }
-  const int ns = coop_slots();
-  int lag = 2;
-  if (const char *l = getenv("CLFA_COOP_LAG")) {
-    int v = atoi(l);
-    if (v >= 1 && v <= 8) lag = v;
-  }
-  CoopCtl *c = (CoopCtl *)ctl;
-  int sm = 1;
-  if (const char *m = getenv("CLFA_COOP_STREAM")) sm = atoi(m);
-#define CLFA_COOP(F, S, M) hipLaunchKernelGGL((k_fft_coop<LOGN, F, S, M>), dim3(grid), dim3(256), 0, s, data, scratch, t.four, batch, c, ns, lag)
-  if (sm == 2) {
-    if (fwd && scale) CLFA_COOP(true, true, 2); else if (fwd) CLFA_COOP(true, false, 2); else CLFA_COOP(false, false, 2);
-  } else if (sm == 0) {
-    if (fwd && scale) CLFA_COOP(true, true, 0); else if (fwd) CLFA_COOP(true, false, 0); else CLFA_COOP(false, false, 0);
-  } else {
-    if (fwd && scale) CLFA_COOP(true, true, 1); else if (fwd) CLFA_COOP(true, false, 1); else CLFA_COOP(false, false, 1);
-  }
-#undef CLFA_COOP
-  return hipGetLastError();
-}
-
-hipError_t launch_fft_coop(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
-                           long batch, const DeviceInfo &di, hipStream_t s) {
-  if (batch <= 0) return hipSuccess;
-  switch (logn) {
-    case 14: return launch_coop_n<14>(fwd, scale, data, scratch, ctl, t, batch, di, s);
-    case 15: return launch_coop_n<15>(fwd, scale, data, scratch, ctl, t, batch, di, s);
-    case 16: return launch_coop_n<16>(fwd, scale, data, scratch, ctl, t, batch, di, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-// reads the error word of the last cooperative launch (0 = no spin ever timed out)
-hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s) {
-  return hipMemcpyAsync(err, &((const CoopCtl *)ctl)->error.v, sizeof(unsigned), hipMemcpyDeviceToHost, s);
-}
 
 // ---------------------------------------------------------------------------------
 // n = 2^17 .. 2^24: beyond the reference's reach (its stage kernel overflows int32 above 65536,
@@ -1500,7 +960,7 @@ static hipError_t launch_big_n1(const BigGeom &g, bool fwd, bool scale, cpx *dat
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (g.logn2 <= kLdsMaxLog) e = launch_fft_lds(g.logn2, fwd, MODE_C2C, false, scratch, sub, batch * N1, di, s);
-  else e = launch_fft_4step(g.logn2, fwd, false, 0, scratch, scratch2, sub, batch * N1, di, s);
+  else e = launch_fft_4step(g.logn2, fwd, false, scratch, scratch2, sub, batch * N1, di, s);
   if (e != hipSuccess) return e;
   const float inv_n = 1.0f / (float)(1L << g.logn);
   if (scale) hipLaunchKernelGGL((k_big_transpose<LOGN1, true>), gt, dim3(256), 0, s, scratch, data, g.logn2, inv_n);

@@ -20,6 +20,7 @@ struct FftTables {      // all device pointers, owned by the plan
   const cpx *half = nullptr;   // W_n^k, k < n/2, forward sign (LDS path; n = complex length)
   const cpx *w2 = nullptr;     // r2c table (cl_fft.cpp:233-238), sign of the plan's direction, m entries
   const cpx *four = nullptr;   // four-step tables: [half N1 | half N2 | lo | hi]
+  const cpx *res16 = nullptr;  // n = 65536 only: tables of the resident kernel (kRes16TabSize entries)
 };
 
 struct DeviceInfo {
@@ -33,11 +34,13 @@ hipError_t launch_fft_lds(int logn, bool fwd, int mode, bool scale, cpx *data, c
                           long batch, const DeviceInfo &di, hipStream_t s);
 const char *name_fft_lds(int logn, bool fwd, int mode);
 
-// four-step FFT, n = 2^logn in (2^kLdsMaxLog, 2^kMaxLog]; scratch = grid * n complex
-int fourstep_grid(int logn, int variant, const DeviceInfo &di);
-hipError_t launch_fft_4step(int logn, bool fwd, bool scale, int variant, cpx *data, cpx *scratch,
-                            const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
-const char *name_fft_4step(int logn, bool fwd, int variant);
+// four-step FFT, n = 2^logn in (2^kLdsMaxLog, 2^kMaxLog]; scratch = fourstep_grid() * n complex
+// (n = 65536 with more than a few transforms runs the resident kernel below and uses the first
+// kRes16SlotBytes * grid bytes of the scratch as its slots)
+int fourstep_grid(const DeviceInfo &di);
+hipError_t launch_fft_4step(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, const FftTables &t, long batch,
+                            const DeviceInfo &di, hipStream_t s);
+const char *name_fft_4step(int logn);
 int fourstep_split(int logn, int *logn1, int *logn2, int *loglo);
 // n = 65536, the whole intermediate resident on the CU (fft_resident.hip): one HBM pass, no scratch.
 // tabs: kRes16TabSize entries, forward sign: [W_256^(t j), t, j < 16 | W_n^k, k < 256 | W_256^k, k < 256 |
@@ -47,22 +50,6 @@ constexpr int kRes16TabSize = 1792;
 constexpr size_t kRes16SlotBytes = 32768;
 hipError_t launch_fft_res16(bool fwd, bool scale, cpx *data, cpx *slots, const cpx *tabs, long batch,
                             const DeviceInfo &di, hipStream_t s);
-// XCD-cooperative four-step (variant 7; selectable, slower than the default): scratch = 8 XCDs x slots x n complex,
-// ctl = a small control block zeroed on the stream before every launch
-constexpr int kVariantCoop = 7;
-size_t coop_ctl_bytes();
-size_t coop_scratch_bytes(int logn);
-hipError_t launch_fft_coop(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
-                           long batch, const DeviceInfo &di, hipStream_t s);
-hipError_t coop_read_error(const void *ctl, unsigned *err, hipStream_t s);
-// readiness-driven cooperative kernel (variant 8)
-constexpr int kVariantCoop2 = 8;
-constexpr int kVariantMax = 9;   // 9: the default four-step shape without LDS-resident rows
-size_t coop2_ctl_bytes();
-hipError_t launch_fft_coop2(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, void *ctl, const FftTables &t,
-                            long batch, const DeviceInfo &di, hipStream_t s);
-hipError_t coop2_read_error(const void *ctl, unsigned *err, hipStream_t s);
-
 // n = 2^17 .. 2^kBigMaxLog (extension: the reference overflows above 65536): columns + rows + transpose
 constexpr int kBigMaxLog = 24;
 struct BigGeom {

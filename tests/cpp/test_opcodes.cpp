@@ -61,6 +61,7 @@ int main() {
     MYFLT tabno = 1, pr = parts, dev = 0, skip = 0, size = 0;
     Inst op(cs, "clconv", ksmps, {aout.data()}, {ain.data(), &tabno, &pr, &dev, &skip, &size});
     CHECK(op.e->init(op.p) == OK);
+    CHECK(op.e->init(op.p) == OK);   // Csound's reinit: init again without deinit (must not leak, must start afresh)
     std::vector<float> coefs(irlen);
     for (int k = 0; k < irlen; k++) coefs[k] = (float)tab[k];
     cl_conv::Clpconv ref(ids[0], irlen, parts);

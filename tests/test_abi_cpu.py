@@ -85,3 +85,25 @@ def test_engine_emulation_on_cpu(tmp_path):
                            "-o", exe])
     out = subprocess.check_output([exe]).decode()
     assert out.strip().endswith("OK"), out
+
+
+def test_resident_kernel_code_object_audit(tmp_path):
+    """fft_resident.hip manages the accumulation registers and v[224:255] by hand; tools/check_isa.py
+    verifies on the freshly compiled ISA that hipcc put nothing of its own there and uses no scratch"""
+    import importlib.util
+    src = os.path.join(ROOT, "opencl_fft_amd", "csrc", "fft_resident.hip")
+    flags = None
+    for ln in open(os.path.join(ROOT, "opencl_fft_amd", "csrc", "Makefile")):
+        if ln.startswith("CXXFLAGS"):
+            flags = ln.split("=", 1)[1].replace("$(ARCH)", "gfx950").split()
+    assert flags, "CXXFLAGS not found in the Makefile"
+    obj = str(tmp_path / "fft_resident.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-save-temps=obj", "-c", src, "-o", obj],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    asm = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
+    assert len(asm) == 1, asm
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    problems = mod.check(str(tmp_path / asm[0]))
+    assert not problems, "\n".join(problems[:10])

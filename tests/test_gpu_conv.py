@@ -243,3 +243,27 @@ def test_pconv_fused_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
                                for b in range(blocks)])
         assert_parity(out[c], want, tol=CTOL, what="channel %d" % c)
     assert (p.wp, p.wp2) == (blocks % nparts, (nparts - 1 - (blocks if tv else 0)) % nparts)
+
+
+def test_pconv_push_ir_device_ragged_cvs():
+    """a (channels, cvs) device tensor with cvs % pts != 0 (96000 / 1024 -> 93 partitions, cl_conv.cpp:143):
+    every channel is read at its own row stride — identical to the host push_ir of the same rows"""
+    import torch
+    pts, cvs, channels, blocks = 1024, 96000, 3, 4
+    rng = np.random.default_rng(17)
+    ir = ((rng.random((channels, cvs), dtype=np.float32) - 0.5) / np.float32(np.sqrt(cvs))).astype(np.float32)
+    x = (rng.random((blocks, channels, pts), dtype=np.float32) * 2 - 1).astype(np.float32)
+    a, b = fa.Clpconv(0, cvs, pts, channels=channels), fa.Clpconv(0, cvs, pts, channels=channels)
+    assert a.nparts == 93 and b.nparts == 93
+    assert a.push_ir(ir) == 0
+    d_ir = torch.from_numpy(ir).cuda()
+    assert b.push_ir_device(d_ir) == 0
+    torch.cuda.synchronize()
+    for blk in range(blocks):
+        oa, ob = np.zeros((channels, pts), np.float32), np.zeros((channels, pts), np.float32)
+        assert a.convolution(oa, x[blk]) == 0 and b.convolution(ob, x[blk]) == 0
+        assert np.array_equal(oa.view(np.uint32), ob.view(np.uint32)), "block %d" % blk
+    # shapes the object cannot take are refused, not read from the wrong offsets
+    assert b.push_ir_device(d_ir[:, :1024]) == -30
+    assert b.push_ir_device(d_ir[:2]) == -30
+    assert b.push_ir_device(d_ir.double()) == -30

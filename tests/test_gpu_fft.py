@@ -134,15 +134,17 @@ def test_cfft_device_resident_batch():
     assert np.max(np.abs(e_out / e_in - 1)) < 1e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
-def test_cfft_large_kernel_variants(variant):
-    n, batch = 65536, 70          # more than grid / 4 transforms: the persistent kernels, not the small-batch pair
-    x = util.lcg_complex(31 + variant, n * batch).reshape(batch, n)
-    plan = fa.Clcfft(0, n, True)
-    assert plan.set_variant(variant) == 0
-    y = x.copy()
-    assert plan.transform(y) == 0
-    assert_parity(y, oracle.cfft(x, True), what="variant %d" % variant)
+def test_cfft_resident_kernel_both_directions():
+    """n = 65536 with more transforms than CUs / 4: the resident kernel (fft_resident.hip), forward and
+    inverse, every transform against the oracle"""
+    n, batch = 65536, 70
+    x = util.lcg_complex(31, n * batch).reshape(batch, n)
+    for fwd in (True, False):
+        plan = fa.Clcfft(0, n, fwd)
+        assert plan.kernel_name() == "k_fft_res16"
+        y = x.copy()
+        assert plan.transform(y) == 0
+        assert_parity(y, oracle.cfft(x, fwd), what="resident kernel fwd=%s" % fwd)
 
 
 @pytest.mark.parametrize("n,batch", [(16384, 70), (16384, 300), (32768, 70), (32768, 300), (65536, 70), (65536, 300)])
@@ -262,21 +264,6 @@ def test_config3_full_size_roundtrip():
     torch.cuda.synchronize()
     err = float((d - orig).double().norm() / orig.double().norm())
     assert err < TOL
-
-
-@pytest.mark.parametrize("n,batch", [(16384, 1), (16384, 37), (32768, 19), (65536, 1), (65536, 2), (65536, 23), (65536, 300)])
-@pytest.mark.parametrize("variant", [7, 8])
-def test_cfft_cooperative_kernel(n, batch, variant):
-    """XCD-cooperative large-N kernels (7: ordered queue, 8: readiness-driven): any batch, both directions"""
-    x = util.lcg_complex(77 + batch, n * batch).reshape(batch, n)
-    for fwd in (True, False):
-        plan = fa.Clcfft(0, n, fwd)
-        assert plan.set_variant(variant) == 0
-        y = x.copy()
-        assert plan.transform(y) == 0
-        assert plan.sync_check() == 0, "a dependency wait timed out inside the cooperative kernel"
-        want = oracle.cfft(x if batch <= 40 else x[::13], fwd)
-        assert_parity(y if batch <= 40 else y[::13], want, what="coop n=%d batch=%d fwd=%s" % (n, batch, fwd))
 
 
 # ---- beyond the reference: n = 2^17 .. 2^24 (SURVEY.md section 8f, row 4) ---------------------------

@@ -141,3 +141,25 @@ def test_device_entry_points_capture_into_a_hip_graph():
     assert_parity(r.cpu().numpy().view(np.complex64), oracle.rfft_forward(r0.cpu().numpy()), what="r2c in graph")
     assert_parity(big.cpu().numpy().view(np.complex64).reshape(8, 65536),
                   oracle.cfft(b0.cpu().numpy().view(np.complex64).reshape(8, 65536), True), what="N=65536 in graph")
+
+
+def test_plan_on_two_streams_is_ordered():
+    """one plan, two caller streams, no synchronisation by the caller: the plan owns one workspace, so
+    the library orders the second stream's work behind the first (clfft_amd.h, conventions)"""
+    import torch
+    from oracle import oracle
+    from tests import util
+    n, batch = 32768, 96   # four-step kernel with a scratch workspace
+    x = util.lcg_complex(5, n * batch).reshape(batch, n)
+    plan = fa.Clcfft(0, n, True)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d1 = torch.from_numpy(x.view(np.float32).copy()).cuda()
+    d2 = d1.clone()
+    torch.cuda.synchronize()
+    assert plan.exec_device(d1, batch, s1.cuda_stream) == 0
+    assert plan.exec_device(d2, batch, s2.cuda_stream) == 0
+    torch.cuda.synchronize()
+    want = oracle.cfft(x[::7], True)
+    for d in (d1, d2):
+        got = d.cpu().numpy().view(np.complex64).reshape(batch, n)[::7]
+        util.assert_parity(got, want, what="two streams")

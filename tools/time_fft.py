@@ -29,13 +29,11 @@ def main():
     src = d.clone()
     ms = timeit(lambda: d.copy_(src))
     print("copy 2GiB->2GiB: %.3f ms = %.2f TB/s (r+w)" % (ms, 2 * d.numel() * 4 / ms / 1e9))
-    for variant in [int(a) for a in sys.argv[1:]] or [0]:
-        plan, inv = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
-        assert plan.set_variant(variant) == 0 and inv.set_variant(variant) == 0
-        d.copy_(src)
-        ms = timeit(alt(plan, inv, d, batch), iters=20)
-        gs = batch * n / ms / 1e6
-        print("variant %d: %.3f ms  %.1f Gsamples/s  alg %.2f TB/s" % (variant, ms, gs, gs * 16 / 1e3), flush=True)
+    plan, inv = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    d.copy_(src)
+    ms = timeit(alt(plan, inv, d, batch), iters=20)
+    gs = batch * n / ms / 1e6
+    print("c2c %d x %d (%s): %.3f ms  %.1f Gsamples/s  alg %.2f TB/s" % (n, batch, plan.kernel_name(), ms, gs, gs * 16 / 1e3), flush=True)
     for size, batch in [(16384, 8192)]:
         x = torch.rand((batch, size), device="cuda") * 2 - 1
         f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
