@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--workload", default="c2c", choices=["c2c", "rfft", "pconv"])
     ap.add_argument("--batch", type=int, default=0, help="override batches / channels per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bandwidth", action="store_true", help="skip the device copy/read/write yardsticks")
+    ap.add_argument("--series-out", default="", help="write the per-launch times (ms) of the timed region to this file")
     return ap.parse_args()
 
 
@@ -158,7 +160,6 @@ def main():
                     "(BASELINE configs[3])" % ch)
         kernel, tkey = "k_pconv_fused", "pconv1024x94"
         metric, unit = "channel-samples/s for partitioned convolution (x1e9)", "Gsamples/s"
-        extra["realtime_ratio_per_channel_denominator_s"] = pts / 48000.0
 
     with torch.cuda.stream(stream):
         for k in range(W):
@@ -189,18 +190,32 @@ def main():
         extra["launch_ms"] = {"fwd_avg": avg_ms, "fwd_min": min(fwd_ms), "fwd_max": max(fwd_ms),
                               "inv_avg": sum(inv_ms) / len(inv_ms), "inv_min": min(inv_ms), "inv_max": max(inv_ms)}
 
+    # The yardsticks the roofline fraction is read against: sustained device
+    # read / write / copy bandwidth, and a copy in the FFT's own access shape (column blocks of 16
+    # columns), measured here, on this device, AFTER the timed region (run before it, 150 ms of copy
+    # kernels leave the chip in a lower clock state and the first ~20 FFT launches read 5-15 % slower).
+    membench = None
+    if not a.no_bandwidth and rank == 0:
+        torch.cuda.synchronize()
+        membench = {k: round(v, 3) for k, v in fa.bandwidth_probe(local, 1 << 30, 100).items()}
+        membench["unit"] = "TB/s"
+        membench["how"] = ("2 x 1 GiB buffers, 100 launches each after 27 warm-up launches; 16-byte non-temporal accesses; "
+                           "copies count read + write; copy_colblock = 128-byte row segments 2 KiB apart (the "
+                           "four-step FFT's global access shape)")
     # parity guard, AFTER the timed region (the oracle's OpenMP pool must not be spinning on the
     # host cores while the HIP runtime threads drive the timed launches): one transform vs the oracle
     if a.workload == "c2c":
         from oracle import oracle
         gq = torch.Generator(device=dev).manual_seed(99)
-        probe = torch.rand((1, 65536, 2), generator=gq, device=dev, dtype=torch.float32) * 2 - 1
-        x0 = probe.cpu().numpy().view(np.complex64).reshape(65536)
+        nprobe = 72      # more transforms than CUs / 4: the same kernel as the timed launches
+        probe = torch.rand((nprobe, 65536, 2), generator=gq, device=dev, dtype=torch.float32) * 2 - 1
+        pick = [0, nprobe - 1]
+        x0 = probe[pick].cpu().numpy().view(np.complex64).reshape(len(pick), 65536)
         # (the INVERSE plan: a different kernel instantiation than the forward one whose launches the
-        # roofline block and the rocprofv3 stats average, so this 1-transform launch does not dilute them)
-        assert plans[1].exec_device(probe, 1, stream.cuda_stream) == 0
+        # roofline block and the rocprofv3 stats average, so this short launch does not dilute them)
+        assert plans[1].exec_device(probe, nprobe, stream.cuda_stream) == 0
         stream.synchronize()
-        y0 = probe.cpu().numpy().view(np.complex64).reshape(65536)
+        y0 = probe[pick].cpu().numpy().view(np.complex64).reshape(len(pick), 65536)
         ref = oracle.cfft(x0, False, nthreads=1)
         extra["parity_relL2_vs_oracle"] = float(np.linalg.norm(y0.astype(np.complex128) - ref) /
                                                 np.linalg.norm(ref.astype(np.complex128)))
@@ -226,6 +241,20 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(tkey),
                          "kernel": kernel, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if membench is not None:
+            rec["membench"] = membench
+            # the same achieved rate against what this device sustains for a plain copy and for a copy
+            # in the FFT's access shape (8000 GB/s, the peak of the roofline block, is the HBM3E spec)
+            rec["roofline"]["frac_of_measured_copy"] = achieved / (membench["copy"] * 1e3)
+            rec["roofline"]["frac_of_measured_colblock_copy"] = achieved / (membench["copy_colblock"] * 1e3)
+        if a.workload == "pconv":
+            # one block = pts / 48 kHz of audio for every channel
+            rec["config"]["realtime_ratio"] = (1024 / 48000.0) / (avg_ms * 1e-3)
+        if a.series_out:
+            with open(a.series_out, "w") as f:
+                f.write("# per-launch ms between HIP events on the launch stream, timed region of: bench.py "
+                        "--workload %s --steps %d --warmup %d\n" % (a.workload, K, W))
+                f.write("\n".join("%.4f" % t for t in per_launch_ms) + "\n")
         if world == 1 and not a.no_cpu_baseline and a.workload == "c2c":
             rec["cpu_baseline"] = cpu_baseline_c2c(65536, 2048)
         else:

@@ -105,6 +105,13 @@ CLFA_API size_t clfa_fft_workspace_bytes(const clfa_fft *plan);
 /* name of the HIP kernel that does the work for this plan (for profiles) */
 CLFA_API const char *clfa_fft_kernel_name(const clfa_fft *plan);
 
+/* measurement aid (nothing of the reference's): sustained device-memory bandwidth in TB/s over
+ * `launches` launches on two buffers of `bytes` each (a multiple of 512 KiB, far beyond the 256 MiB
+ * Infinity Cache for a meaningful number).  what: 0 read, 1 write, 2 copy (all 16-byte non-temporal
+ * accesses, contiguous), 3 copy in the four-step FFT's own shape (256 x 256 matrices of 8-byte elements
+ * moved in blocks of 16 columns: 128-byte segments 2 KiB apart).  Copies count bytes read + written. */
+CLFA_API int clfa_bandwidth_probe(int device, int what, size_t bytes, int launches, double *tb_per_s);
+
 /* the reference's `reorder` kernel as a stand-alone op (cl_fft.cpp:24-27):
  * out[b*n + k] = in[b*n + bitrev(k)], exact gather of complex64, out != in */
 CLFA_API int clfa_reorder_dev(int device, void *out, const void *in, int n, long batch, void *stream);

@@ -171,6 +171,19 @@ class Clrfft(_Plan):
         return lib().clfa_rfft_transform(self._h, c.ctypes.data, rp, c.size // self.N)
 
 
+def bandwidth_probe(device_id=0, nbytes=1 << 30, launches=100):
+    """sustained device-memory bandwidth in TB/s: {"read", "write", "copy", "copy_colblock"} — the
+    yardsticks for the roofline fractions (clfa_bandwidth_probe in clfft_amd.h)"""
+    out = {}
+    for what, name in enumerate(("read", "write", "copy", "copy_colblock")):
+        v = C.c_double(0.0)
+        e = lib().clfa_bandwidth_probe(int(device_id), what, int(nbytes), int(launches), C.byref(v))
+        if e != CL_SUCCESS:
+            raise RuntimeError("bandwidth probe: " + cl_error_string(e))
+        out[name] = v.value
+    return out
+
+
 class Clpconv:
     """cl_conv::Clpconv(device_id, cvs, pts, errs=NULL, uData=NULL, ...) (cl_conv.h:124-188)
 

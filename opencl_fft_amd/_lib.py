@@ -39,6 +39,7 @@ SYMBOLS = [
     ("clfa_pconv_wp2", C.c_int, [_vp]),
     ("clfa_pconv_push_ir", C.c_int, [_vp, _vp]),
     ("clfa_pconv_push_ir_dev", C.c_int, [_vp, _vp, C.c_long, _vp]),
+    ("clfa_bandwidth_probe", C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     ("clfa_pconv_convolution", C.c_int, [_vp, _vp, _vp]),
     ("clfa_pconv_convolution_tv", C.c_int, [_vp, _vp, _vp, _vp]),
     ("clfa_pconv_process_dev", C.c_int, [_vp, _vp, _vp, _vp, _vp]),

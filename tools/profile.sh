@@ -7,8 +7,11 @@ TAG=${1:-r01}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline $*"
-python3 bench.py $ARGS > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err" || exit 1
+ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-bandwidth $*"
+# the driver's command line first (20 steps, 5 warm-up, yardsticks included), with its per-launch series
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --series-out "$OUT/series_steps20.txt" $* > "$OUT/bench_driver_cmdline.json" 2> "$OUT/bench_unprofiled.err" || exit 1
+echo "== driver command line"; cat "$OUT/bench_driver_cmdline.json"
+python3 bench.py $ARGS --series-out "$OUT/series_steps100.txt" > "$OUT/bench_unprofiled.json" 2>> "$OUT/bench_unprofiled.err" || exit 1
 echo "== unprofiled"; cat "$OUT/bench_unprofiled.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS > "$OUT/stats.log" 2>&1 || { tail -5 "$OUT/stats.log"; exit 2; }
 echo "== stats done"
