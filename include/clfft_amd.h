@@ -24,7 +24,9 @@
  * everywhere in HIP).  Work is ordered by that stream only; nothing blocks.
  * A plan / convolution object owns ONE device workspace, so it may have work in flight on one
  * stream at a time: when a call names another stream than the object's previous call, the library
- * first waits (on the host) for that previous stream.  Every entry point leaves the calling
+ * first waits (on the host) for that previous stream (not while the new stream is being captured into
+ * a hipGraph: a captured launch is ordered by its graph, and the object's earlier work must be complete
+ * when the graph is replayed).  Every entry point leaves the calling
  * thread's current HIP device as it found it.
  */
 #ifndef CLFFT_AMD_H

@@ -77,7 +77,14 @@ struct StreamOrder {
   bool any = false;
   hipError_t use(hipStream_t s) {
     hipError_t e = hipSuccess;
-    if (any && s != last) e = hipStreamSynchronize(last);
+    if (any && s != last) {
+      // a stream under hipGraph capture must not be waited for (nor may anything else be while it
+      // captures): captured launches are ordered by the graph, and whatever the object was doing
+      // before the capture has to be complete when the graph is replayed — the caller's contract
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &st) != hipSuccess) (void)hipGetLastError();
+      if (st == hipStreamCaptureStatusNone) e = hipStreamSynchronize(last);
+    }
     last = s;
     any = true;
     return e;

@@ -103,9 +103,46 @@ struct PeekCfft : cl_fft::Clcfft {
   }
 };
 
+// ---- G11: direct convolution over several ring cycles -------------------------
+// With irsize % vsize == 0 the reference's write point takes the values 0, vsize, ..., irsize only,
+// so its defective `wp > irsize` branch (cl_dconv.cpp:112-119) never runs; the delay ring (and, in
+// the two-input form, the coefficient ring) is uninitialised device memory only until every slot
+// has been written once, i.e. from block irsize / vsize + 1 on the output is fully defined.
+static void run_g11(cl_device_id dev) {
+  auto run_dconv = [&](const std::string &tag, int irsize, int vsize, int blocks, bool tv) {
+    cl_conv::Cldconv c(dev, irsize, vsize);
+    if (c.get_cl_err() != CL_SUCCESS) {
+      fprintf(stderr, "Cldconv setup error %d\n", c.get_cl_err());
+      exit(6);
+    }
+    Lcg r(tv ? 13 : 11);
+    std::vector<float> ir(irsize), in(blocks * vsize), in2(blocks * vsize), out(blocks * vsize);
+    for (auto &v : ir) v = r.half();
+    for (auto &v : in) v = r.half();
+    for (auto &v : in2) v = r.half();
+    c.push_ir(ir.data());
+    for (int b = 0; b < blocks; b++) {
+      if (tv) c.convolution(&out[b * vsize], &in[b * vsize], &in2[b * vsize]);
+      else c.convolution(&out[b * vsize], &in[b * vsize]);
+    }
+    const std::string from = std::to_string(irsize / vsize + 1);
+    put_f32(tag + "_ir", ir.data(), ir.size(), "impulse response (push_ir)");
+    put_f32(tag + "_in", in.data(), in.size(), "input blocks");
+    if (tv) put_f32(tag + "_in2", in2.data(), in2.size(), "second input blocks");
+    put_f32(tag + "_out", out.data(), out.size(),
+            std::string(tv ? "Cldconv::convolution(out,in1,in2)" : "Cldconv::convolution(out,in)") +
+                " per block; independent of uninitialised device memory from block " + from + " on");
+  };
+  run_dconv("g11_dconv_i16_v8", 16, 8, 12, false);      // 3 ring slots, 4 cycles
+  run_dconv("g11_dconv_i1024_v64", 1024, 64, 56, false);  // 17 ring slots, > 3 cycles
+  run_dconv("g11_dconv_i64_v64", 64, 64, 8, false);       // 2 ring slots
+  run_dconv("g11_tvdconv_i16_v8", 16, 8, 12, true);
+  run_dconv("g11_tvdconv_i256_v32", 256, 32, 30, true);
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: ref_driver <outdir> [device-index]\n");
+    fprintf(stderr, "usage: ref_driver <outdir> [device-index] [g11]\n");
     return 2;
   }
   g_dir = argv[1];
@@ -122,9 +159,17 @@ int main(int argc, char **argv) {
   fprintf(stderr, "ref_driver: %u device(s), using %d: %s\n", num, devidx, name);
   cl_device_id dev = ids[devidx];
 
-  g_manifest = fopen((g_dir + "/manifest.json").c_str(), "w");
+  const bool only11 = argc > 3 && !strcmp(argv[3], "g11");   // only the G11 vectors (manifest_g11.json)
+  g_manifest = fopen((g_dir + (only11 ? "/manifest_g11.json" : "/manifest.json")).c_str(), "w");
   fprintf(g_manifest, "{\n  \"_device\": \"%s\"", name);
   g_first = false;
+  if (only11) {
+    run_g11(dev);
+    fprintf(g_manifest, "\n}\n");
+    fclose(g_manifest);
+    fprintf(stderr, "ref_driver: G11 done\n");
+    return 0;
+  }
 
   const double PI = cl_fft::PI;
 
@@ -320,6 +365,7 @@ int main(int argc, char **argv) {
     put_f32("g10_dconv_out", out.data(), out.size(),
             "Cldconv::convolution; depends on uninitialised device memory in the reference");
   }
+  run_g11(dev);
   // ---- timing of the reference's own path on this device ----------------
   {
     const int N = 65536, reps = 20;

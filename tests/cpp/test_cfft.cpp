@@ -4,6 +4,8 @@
 // cl_fft::Clcfft, get_error, transform, cl_error_string.
 #include <cl_fft.h>
 
+#include "golden.h"
+
 #include <cmath>
 #include <cstdio>
 #include <iomanip>
@@ -54,6 +56,30 @@ int main() {
   for (int k = 0; k < 5; k++) big.transform(b.data() + 1024 * k);
   for (size_t i = 0; i < a.size(); i++)
     if (a[i] != b[i]) bad++;
+  // config 1 of BASELINE.json: N = 1024 through the class surface against the reference's own outputs
+  // (G3: input LCG(12345), forward / inverse / round trip of the unmodified reference)
+  {
+    Clcfft f1k(device_ids[DEVID], 1024, true), i1k(device_ids[DEVID], 1024, false);
+    golden::Lcg r(12345);
+    std::vector<std::complex<float>> x(1024);
+    for (auto &c : x) {
+      float re = r.sym();
+      float im = r.sym();
+      c = std::complex<float>(re, im);
+    }
+    std::vector<std::complex<float>> y = x, z = x;
+    if (f1k.transform(y.data()) != 0 || i1k.transform(z.data()) != 0) return 1;
+    std::vector<std::complex<float>> rt = y;
+    if (i1k.transform(rt.data()) != 0) return 1;
+    const std::vector<float> gf = golden::load_f32("g3_cfft1024_fwd"), gi = golden::load_f32("g3_cfft1024_inv"),
+                             gr = golden::load_f32("g3_cfft1024_rt");
+    if (gf.size() != 2048 || gi.size() != 2048 || gr.size() != 2048) bad++;
+    else {
+      bad += !golden::parity(reinterpret_cast<float *>(y.data()), gf.data(), 2048, 1e-6, "Clcfft 1024 forward vs reference");
+      bad += !golden::parity(reinterpret_cast<float *>(z.data()), gi.data(), 2048, 1e-6, "Clcfft 1024 inverse vs reference");
+      bad += !golden::parity(reinterpret_cast<float *>(rt.data()), gr.data(), 2048, 1e-6, "Clcfft 1024 round trip vs reference");
+    }
+  }
   // error convention: a bad size is reported through get_error(), nothing throws
   Clcfft wrong(device_ids[DEVID], 1000, true);
   if (wrong.get_error() != CL_INVALID_VALUE || std::string(cl_error_string(wrong.get_error())) != "Invalid value") bad++;

@@ -4,6 +4,8 @@
 // we instead compare against the per-block closed form (Y[0]*=0.5, Y[pts]*=0.5) evaluated by DFT.
 #include <cl_dconv.h>
 
+#include "golden.h"
+
 #include <cmath>
 #include <complex>
 #include <iostream>
@@ -80,6 +82,33 @@ int main() {
     for (int k = 0; k < irsize; k++)
       if (n - 1 - k >= 0) want += (double)h[k] * x[n - 1 - k];
     if (std::fabs(want - y[n]) > 2e-6) bad++;
+  }
+  // the reference's own outputs through the class surface: G8 (Clpconv, pts 1024, 8 partitions, 24 blocks:
+  // the ring wraps twice) and G11 (Cldconv over four ring cycles, every fully defined block)
+  {
+    const std::vector<float> gir = golden::load_f32("g8_pconv_p1024_n8_ir"), gin = golden::load_f32("g8_pconv_p1024_n8_in"),
+                             gout = golden::load_f32("g8_pconv_p1024_n8_out");
+    if (gir.size() != 8192 || gin.size() != 24576 || gout.size() != 24576) bad++;
+    else {
+      cl_conv::Clpconv c8(ids[0], 8192, 1024);
+      std::vector<float> irv = gir, inv = gin, o(24576);
+      if (c8.get_cl_err() != CL_SUCCESS || c8.push_ir(irv.data()) != CL_SUCCESS) return 1;
+      for (int b = 0; b < 24; b++)
+        if (c8.convolution(&o[b * 1024], &inv[b * 1024]) != CL_SUCCESS) return 1;
+      bad += !golden::parity(o.data(), gout.data(), o.size(), 2e-6, "Clpconv 1024 x 8 vs reference");
+    }
+    const std::vector<float> dir_ = golden::load_f32("g11_dconv_i16_v8_ir"), din = golden::load_f32("g11_dconv_i16_v8_in"),
+                             dout = golden::load_f32("g11_dconv_i16_v8_out");
+    if (dir_.size() != 16 || din.size() != 96 || dout.size() != 96) bad++;
+    else {
+      cl_conv::Cldconv d11(ids[0], 16, 8);
+      std::vector<float> irv = dir_, inv = din, o(96);
+      if (d11.push_ir(irv.data()) != CL_SUCCESS) return 1;
+      for (int b = 0; b < 12; b++)
+        if (d11.convolution(&o[b * 8], &inv[b * 8]) != CL_SUCCESS) return 1;
+      // blocks 0..2 of the reference depend on its uninitialised device memory (cl_dconv.cpp:87-91)
+      bad += !golden::parity(o.data() + 24, dout.data() + 24, 72, 1e-6, "Cldconv 16 / 8 vs reference");
+    }
   }
   // error callback by value on a bad geometry
   cl_conv::Clpconv wrong(ids[0], 100, 24, on_err, (void *)&g_msgs);

@@ -2,6 +2,8 @@
 // expected packed spectrum (0.5,0.5) (0,-1) 0 0 0 0 0 0, inverse returns the input.
 #include <cl_fft.h>
 
+#include "golden.h"
+
 #include <cmath>
 #include <iomanip>
 #include <iostream>
@@ -46,6 +48,35 @@ int main() {
   if (base->transform(buf.data()) != 0) return 1;
   for (int i = 0; i < N / 2; i++)
     if (std::abs(buf[i] - spec[i]) > 1e-6f) bad++;
+  // size 2048 against the reference's own outputs (G5: LCG(12345) forward, round trip; inverse of the
+  // arbitrary packed spectrum LCG(777)) — includes the un-conjugated self-paired bin M/2
+  {
+    const int S = 2048, M = S / 2;
+    Clrfft f(device_ids[DEVID], S, true), inv(device_ids[DEVID], S, false);
+    golden::Lcg r(12345);
+    std::vector<float> x(S), back(S), arbout(S);
+    for (auto &v : x) v = r.sym();
+    std::vector<std::complex<float>> sp(M);
+    if (f.transform(sp.data(), x.data()) != 0) return 1;
+    std::vector<std::complex<float>> tmp = sp;
+    if (inv.transform(tmp.data(), back.data()) != 0) return 1;
+    golden::Lcg r2(777);
+    std::vector<std::complex<float>> arb(M);
+    for (auto &c : arb) {
+      float re = r2.sym();
+      float im = r2.sym();
+      c = std::complex<float>(re, im);
+    }
+    if (inv.transform(arb.data(), arbout.data()) != 0) return 1;
+    const std::vector<float> gf = golden::load_f32("g5_rfft2048_fwd"), gr = golden::load_f32("g5_rfft2048_rt"),
+                             ga = golden::load_f32("g5_rfft2048_invarb");
+    if (gf.size() != (size_t)S || gr.size() != (size_t)S || ga.size() != (size_t)S) bad++;
+    else {
+      bad += !golden::parity(reinterpret_cast<float *>(sp.data()), gf.data(), S, 1e-6, "Clrfft 2048 forward vs reference");
+      bad += !golden::parity(back.data(), gr.data(), S, 1e-6, "Clrfft 2048 round trip vs reference");
+      bad += !golden::parity(arbout.data(), ga.data(), S, 1e-6, "Clrfft 2048 inverse (arbitrary) vs reference");
+    }
+  }
   std::cout << (bad ? "FAIL" : "OK") << std::endl;
   return bad ? 1 : 0;
 }

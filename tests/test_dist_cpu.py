@@ -71,3 +71,89 @@ def test_two_rank_gloo_sharded_fft(tmp_path, total):
         assert abs(m[0] - e) <= 1e-9 * e          # checksum of checksums agrees on every rank
         assert m[1] == 2.0                        # max over ranks of (1 + rank)
     assert [int(m[3]) for m in metas] == [c for _, c in (shard_range(total, r, world) for r in range(world))]
+
+
+# ---- eight ranks, the product's own Python path, the library mocked at the launch boundary -----------
+class _FakeLib:
+    """stands in for libclfft_amd.so below opencl_fft_amd.Clcfft: the same entry points the wrapper
+    calls, with the launch (clfa_fft_exec_dev) done by numpy on host memory.  Everything above the C ABI
+    — plan objects, status codes, pointer / batch arithmetic, ShardedBatch — is the product's code."""
+
+    def __init__(self):
+        self.plans, self.launches = {}, []
+
+    def clfa_cfft_create(self, href, device, n, forward):
+        import ctypes
+        h = len(self.plans) + 1
+        self.plans[h] = (int(n), bool(forward))
+        ctypes.cast(href, ctypes.POINTER(ctypes.c_void_p))[0] = h
+        return 0
+
+    def clfa_fft_get_error(self, h):
+        return 0
+
+    def clfa_fft_get_log(self, h):
+        return b""
+
+    def clfa_fft_destroy(self, h):
+        pass
+
+    def clfa_fft_exec_dev(self, h, ptr, batch, stream):
+        import ctypes
+        n, fwd = self.plans[getattr(h, "value", h)]
+        buf = (ctypes.c_float * (2 * n * batch)).from_address(int(ptr))
+        a = np.frombuffer(buf, dtype=np.complex64).reshape(batch, n)
+        a[...] = (np.fft.fft(a, axis=-1) / n if fwd else np.fft.ifft(a, axis=-1) * n).astype(np.complex64)
+        self.launches.append((n, batch))
+        return 0
+
+
+def _worker8(rank, world, port, total, n, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import opencl_fft_amd as fa
+    from opencl_fft_amd.dist import ShardedBatch
+    from tests import util
+    fake = _FakeLib()
+    fa.lib = lambda: fake                       # the launch boundary
+    sb = ShardedBatch(total)
+    x = util.lcg_complex(77, total * n).reshape(total, n)
+    mine = torch.from_numpy(np.ascontiguousarray(x[sb.slice()]).view(np.float32).copy())
+    plan = fa.Clcfft(0, n, True)
+    assert plan.get_error() == 0
+    sb.barrier()
+    if sb.count:
+        assert plan.exec_device(mine, sb.count, stream=0) == 0
+    y = mine.numpy().view(np.complex64).reshape(sb.count, n)
+    energy = float(np.sum(np.abs(y.astype(np.complex128)) ** 2))
+    tot = float(sb.reduce_sum(energy).item())
+    tmax = sb.reduce_max(0.5 + 0.25 * rank)     # "elapsed" of this rank; bench.py reports the max
+    np.save(os.path.join(out_dir, "y%d.npy" % rank), y)
+    np.save(os.path.join(out_dir, "meta%d.npy" % rank),
+            np.array([tot, tmax, sb.start, sb.count, len(fake.launches), sum(b for _, b in fake.launches)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [32, 37, 5])
+def test_eight_rank_gloo_product_path(tmp_path, total):
+    """config 5's shape on CPU: 8 ranks, contiguous shards (ragged and fewer-than-ranks totals included),
+    no data-path collective, checksum and max-time reductions as bench.py does with RCCL"""
+    import torch.multiprocessing as mp
+    from tests import util
+    world, n = 8, 512
+    port = _free_port()
+    mp.spawn(_worker8, args=(world, port, total, n, str(tmp_path)), nprocs=world, join=True)
+    x = util.lcg_complex(77, total * n).reshape(total, n)
+    want = (np.fft.fft(x, axis=-1) / n).astype(np.complex64)
+    parts = [np.load(tmp_path / ("y%d.npy" % r)) for r in range(world)]
+    metas = [np.load(tmp_path / ("meta%d.npy" % r)) for r in range(world)]
+    got = np.concatenate(parts, axis=0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "union of the shards != unsharded result"
+    e = float(np.sum(np.abs(want.astype(np.complex128)) ** 2))
+    for r, m in enumerate(metas):
+        assert abs(m[0] - e) <= 1e-9 * e                      # every rank holds the same global checksum
+        assert m[1] == 0.5 + 0.25 * (world - 1)               # max over ranks
+        assert (int(m[2]), int(m[3])) == shard_range(total, r, world)
+        assert int(m[5]) == int(m[3]) and int(m[4]) == (1 if m[3] else 0)   # one launch over the rank's own batches

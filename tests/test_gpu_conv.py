@@ -155,6 +155,26 @@ def test_dconv_vs_reference_and_oracle():
     assert_parity(np.concatenate(outs), golden("g10_dconv_out"), tol=CTOL, what="vs reference")
 
 
+@pytest.mark.parametrize("tag,irsize,vsize,tv", [("g11_dconv_i16_v8", 16, 8, False), ("g11_dconv_i1024_v64", 1024, 64, False),
+                                                 ("g11_dconv_i64_v64", 64, 64, False), ("g11_tvdconv_i16_v8", 16, 8, True),
+                                                 ("g11_tvdconv_i256_v32", 256, 32, True)])
+def test_dconv_vs_reference_over_ring_cycles(tag, irsize, vsize, tv):
+    """G11 (tests/test_oracle_golden.py): HIP Cldconv against the unmodified reference over several ring
+    cycles, every block from the first one that no longer depends on the reference's uninitialised memory"""
+    ir, x, ref = golden(tag + "_ir"), golden(tag + "_in"), golden(tag + "_out")
+    x2 = golden(tag + "_in2") if tv else None
+    d = fa.Cldconv(0, irsize, vsize)
+    assert d.get_cl_err() == 0 and d.push_ir(ir) == 0
+    tol = max(1e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24)   # the reference's CAS-atomic sum is order-dependent
+    first = irsize // vsize + 1
+    for b in range(x.size // vsize):
+        sl = slice(b * vsize, (b + 1) * vsize)
+        out = np.zeros(vsize, np.float32)
+        assert (d.convolution(out, x[sl], x2[sl]) if tv else d.convolution(out, x[sl])) == 0
+        if b >= first:
+            assert_parity(out, ref[sl], tol=tol, what="%s block %d" % (tag, b))
+
+
 @pytest.mark.parametrize("irsize,vsize,blocks", [(16, 8, 9), (1000, 64, 40), (5, 7, 6), (4096, 32, 10)])
 def test_dconv_ring_wrap_vs_oracle(irsize, vsize, blocks):
     s = util.lcg_half(3, irsize + vsize * blocks)
@@ -243,6 +263,32 @@ def test_pconv_fused_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
                                for b in range(blocks)])
         assert_parity(out[c], want, tol=CTOL, what="channel %d" % c)
     assert (p.wp, p.wp2) == (blocks % nparts, (nparts - 1 - (blocks if tv else 0)) % nparts)
+
+
+def test_config4_full_size_ring_wraps():
+    """config 4 at full size for 110 blocks — the ring of 94 spectra wraps — eight channels against the
+    oracle on every block, ring indices as the reference's (cl_conv.cpp:424)"""
+    import torch
+    pts, cvs, channels, blocks = 1024, 96256, 256, 110
+    g = torch.Generator(device="cuda").manual_seed(44)
+    ir = (torch.rand((channels, cvs), generator=g, device="cuda") - 0.5) / (cvs ** 0.5)
+    x = torch.rand((blocks, channels, pts), generator=g, device="cuda") * 2 - 1
+    p = fa.Clpconv(0, cvs, pts, channels=channels)
+    assert p.get_cl_err() == 0 and p.nparts == 94
+    assert p.push_ir_device(ir) == 0
+    y = torch.empty((blocks, channels, pts), device="cuda")
+    for b in range(blocks):
+        assert p.process_device(y[b], x[b]) == 0
+    torch.cuda.synchronize()
+    assert (p.wp, p.wp2) == (blocks % 94, 93)
+    pick = [0, 1, 31, 100, 128, 199, 254, 255]
+    ir_h, x_h, y_h = ir[pick].cpu().numpy(), x[:, pick].cpu().numpy(), y[:, pick].cpu().numpy()
+    for k, c in enumerate(pick):
+        o = oracle.Pconv(cvs, pts)
+        o.push_ir(ir_h[k])
+        want = np.stack([o.convolution(x_h[b, k]) for b in range(blocks)])
+        assert_parity(y_h[:, k], want, tol=CTOL, what="channel %d, all blocks" % c)
+        assert_parity(y_h[94:, k], want[94:], tol=CTOL, what="channel %d, blocks after the wrap" % c)
 
 
 def test_pconv_push_ir_device_ragged_cvs():

@@ -311,6 +311,35 @@ def test_dconv_vs_reference_first_blocks():
     assert_parity(out, ref, tol=2e-6, what="dconv")
 
 
+G11 = [("g11_dconv_i16_v8", 16, 8, False), ("g11_dconv_i1024_v64", 1024, 64, False), ("g11_dconv_i64_v64", 64, 64, False),
+       ("g11_tvdconv_i16_v8", 16, 8, True), ("g11_tvdconv_i256_v32", 256, 32, True)]
+
+
+def dconv_tol(irsize):
+    """The reference sums its irsize taps by float CAS atomics in arbitrary order (cl_dconv.cpp:17-31,42):
+    its own result moves by ~sqrt(irsize) ulp between runs, so the bar is 2 sqrt(irsize) ulp
+    (1e-6 up to 64 taps)."""
+    return max(1e-6, 2.0 * np.sqrt(irsize) * 2.0 ** -24)
+
+
+@pytest.mark.parametrize("tag,irsize,vsize,tv", G11)
+def test_dconv_vs_reference_over_ring_cycles(tag, irsize, vsize, tv):
+    """G11: the unmodified reference with irsize % vsize == 0 (its defective wrap branch never runs) over
+    more than three ring cycles; from block irsize / vsize + 1 on nothing depends on the uninitialised
+    device memory of cl_dconv.cpp:87-91 any more, and the oracle must agree block for block"""
+    ir, x, ref = golden(tag + "_ir"), golden(tag + "_in"), golden(tag + "_out")
+    x2 = golden(tag + "_in2") if tv else None
+    d = oracle.Dconv(irsize, vsize)
+    d.push_ir(ir)
+    first, blocks = irsize // vsize + 1, x.size // vsize
+    assert blocks >= 3 * first or irsize == 1024
+    for b in range(blocks):
+        sl = slice(b * vsize, (b + 1) * vsize)
+        out = d.convolution(x[sl], x2[sl]) if tv else d.convolution(x[sl])
+        if b >= first:
+            assert_parity(out, ref[sl], tol=dconv_tol(irsize), what="%s block %d" % (tag, b))
+
+
 def test_dconv_is_fir_with_one_sample_latency():
     """kernel cl_dconv.cpp:32-43: y[n] = sum_k coefs[k] x[n-1-k] (ring read point)"""
     irsize, vsize, blocks = 16, 8, 9     # crosses the ring wrap several times
