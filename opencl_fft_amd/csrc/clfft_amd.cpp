@@ -407,13 +407,14 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
   }
   if (rowlog <= kLdsMaxLog) {
     if (kLdsTwoLevel(rowlog)) {
-      // two-level table: hi[j] = W_n^(64 j), j < n/64, then lo[j] = W_n^j, j < 64
-      const int lo = 1 << kLdsTwoLevelLogLo;
-      std::vector<cpx> part;
-      fill_twiddle(h, rown / lo, rown, lo, -1.f);
-      fill_twiddle(part, lo, rown, 1, -1.f);
-      h.resize(rown / lo);
-      h.insert(h.end(), part.begin(), part.begin() + lo);
+      // n = 8192: lane-addressed tables (internal.hpp, kLane13Size), every value rounded from double
+      h.clear();
+      auto w = [&](long k, long n) { h.push_back(mk((float)cos(k * 2 * kPI / n), -(float)sin(k * 2 * kPI / n))); };
+      for (int j = 0; j < 16; j++)
+        for (int t = 0; t < 16; t++) w(j * t, 256);
+      for (int k = 0; k < 4; k++)
+        for (int j = 0; j < 256; j++) w(((1 << k) * j) & 4095, 4096);
+      for (int t = 0; t < 512; t++) w(t, 8192);
     } else {
       fill_twiddle(h, rown / 2, rown, 1, -1.f);
     }

@@ -17,6 +17,7 @@
 // The header is also host-compilable (CLFA_HD) so tests/cpp/emulate_engine.cpp
 // can run the same pass code on the CPU, lane by lane.
 #pragma once
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -316,12 +317,88 @@ template <int LOGN, bool FWD, int LOGLO> CLFA_HD cpx cmul_tw(cpx v, const TwoLev
   return cmulc<!FWD>(v, cmul(tab.hi[k >> LOGLO], tab.lo[k & ((1 << LOGLO) - 1)]));
 }
 
+// ---- n = 8192: twiddles addressed by lane constants ------------------------------------------------
+// The two-level table costs ~6 integer instructions and two LDS reads per twiddle (a third of the
+// 8192-point kernel's instruction stream was index arithmetic).  Every pass's twiddles are powers of
+// ONE value per lane, so for the pass structure 16 x 16 x 16 x 2 (16 points per lane, 512 lanes):
+//   pass 2 (NS = 16)   W_256^(jm t), jm = tid & 15: row jm of a 16 x 16 table — one base address per
+//                      lane, the 15 reads use immediate offsets;
+//   pass 3 (NS = 256)  W_4096^(jm t), jm = tid & 255: the powers t = 1..15 of W_4096^jm as products
+//                      of four exact table values W_4096^(jm), ^(2 jm), ^(4 jm), ^(8 jm) (at most three
+//                      multiplications deep);
+//   pass 4 (radix 2)   W_8192^(tid + 512 u) = W_8192^tid * W_16^u: a lane constant times compile-time
+//                      constants.
+// No integer arithmetic at all; the LDS table has 1280 entries.
+struct LaneTab13 {
+  const cpx *row16;   // LDS: W_256^((tid & 15) t), t = 0..15
+  const cpx *s256;    // LDS: [256 k] = W_4096^(2^k (tid & 255)), k = 0..3 (exponent taken mod 4096)
+  cpx w;              // W_8192^tid (forward sign, like every table)
+};
+constexpr float kC16t[8] = {1.0f, 0.92387953251128675613f, 0.70710678118654752440f, 0.38268343236508977173f, 0.0f,
+                            -0.38268343236508977173f, -0.70710678118654752440f, -0.92387953251128675613f};
+constexpr float kS16t[8] = {0.0f, 0.38268343236508977173f, 0.70710678118654752440f, 0.92387953251128675613f, 1.0f,
+                            0.92387953251128675613f, 0.70710678118654752440f, 0.38268343236508977173f};
+// W_8192^(tid + 512 u), forward sign
+template <int U8> CLFA_HD cpx lane_w13(const LaneTab13 &tab) {
+  if constexpr (U8 == 0) return tab.w;
+  else return ctw<true>(tab.w, kC16t[U8], kS16t[U8]);
+}
+// the twiddles of the pass that starts at 2^LOGNS on elements v[u + U t], t >= 1 (DIT: before the
+// butterflies; transposed chain: after them) — forward: times W, inverse: times conj(W)
+template <int LOGNS, bool FWD> CLFA_HD void lane_tw13(cpx (&v)[16], const LaneTab13 &tab) {
+  if constexpr (LOGNS == 4) {
+    v[1] = cmulc<!FWD>(v[1], tab.row16[1]);
+#pragma unroll
+    for (int t = 2; t < 16; t += 2) cmulc2<!FWD>(v[t], v[t + 1], v[t], tab.row16[t], v[t + 1], tab.row16[t + 1]);
+  } else if constexpr (LOGNS == 8) {
+    const cpx s1 = tab.s256[0], s2 = tab.s256[256], s4 = tab.s256[512], s8 = tab.s256[768];
+    cpx p3, p5, p6, p7;
+    cmulc2(p3, p5, s1, s2, s1, s4);
+    cmulc2(p6, p7, s2, s4, p3, s4);
+    cmulc2<!FWD>(v[1], v[2], v[1], s1, v[2], s2);
+    cmulc2<!FWD>(v[3], v[4], v[3], p3, v[4], s4);
+    cmulc2<!FWD>(v[5], v[6], v[5], p5, v[6], p6);
+    cmulc2<!FWD>(v[7], v[8], v[7], p7, v[8], s8);
+    // t = 8 + r: (v * P_r) * s8 — as many multiplications as forming P_(8+r) first, fewer registers
+    cmulc2<!FWD>(v[9], v[10], v[9], s1, v[10], s2);
+    cmulc2<!FWD>(v[11], v[12], v[11], p3, v[12], s4);
+    cmulc2<!FWD>(v[13], v[14], v[13], p5, v[14], p6);
+    v[15] = cmulc<!FWD>(v[15], p7);
+    cmulc2<!FWD>(v[9], v[10], v[9], s8, v[10], s8);
+    cmulc2<!FWD>(v[11], v[12], v[11], s8, v[12], s8);
+    cmulc2<!FWD>(v[13], v[14], v[13], s8, v[14], s8);
+    v[15] = cmulc<!FWD>(v[15], s8);
+  } else {
+    static_assert(LOGNS == 12, "passes of the 8192-point transform");
+    cmulc2<!FWD>(v[8], v[9], v[8], lane_w13<0>(tab), v[9], lane_w13<1>(tab));
+    cmulc2<!FWD>(v[10], v[11], v[10], lane_w13<2>(tab), v[11], lane_w13<3>(tab));
+    cmulc2<!FWD>(v[12], v[13], v[12], lane_w13<4>(tab), v[13], lane_w13<5>(tab));
+    cmulc2<!FWD>(v[14], v[15], v[14], lane_w13<6>(tab), v[15], lane_w13<7>(tab));
+  }
+}
+// paired radix-2 pass (pass_last_paired / pass_first_paired, NB = 4096): element u + 8 belongs to
+// butterfly j = tid + 512 u (twiddle W^j), element u + 4 + 8 to its partner NB - j (twiddle
+// W^(4096 - j) = -conj(W^j)); lane 0's u = 0 pairs butterflies 0 and NB/2 = 2048 (W^2048 = -i)
+template <bool FWD> CLFA_HD void lane_tw13_paired(cpx (&v)[16], int tid, const LaneTab13 &tab) {
+  const cpx w0 = lane_w13<0>(tab), w1 = lane_w13<1>(tab), w2 = lane_w13<2>(tab), w3 = lane_w13<3>(tab);
+  cpx q0 = mk(-w0.x, w0.y);
+  const cpx q1 = mk(-w1.x, w1.y), q2 = mk(-w2.x, w2.y), q3 = mk(-w3.x, w3.y);
+  if (tid == 0) q0 = mk(0.f, -1.f);
+  cmulc2<!FWD>(v[8], v[9], v[8], w0, v[9], w1);
+  cmulc2<!FWD>(v[10], v[11], v[10], w2, v[11], w3);
+  cmulc2<!FWD>(v[12], v[13], v[12], q0, v[13], q1);
+  cmulc2<!FWD>(v[14], v[15], v[14], q2, v[15], q3);
+}
+
 // One pass on the registers of lane `tid`: input twiddles then U butterflies.
 template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
 CLFA_HD void pass_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
   constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
   constexpr int E = 1 << LOGE, R = 1 << LOGR, U = E / R, T = 1 << (LOGN - LOGE), NS = 1 << LOGNS;
-  if constexpr (LOGNS > 0) {
+  if constexpr (LOGNS > 0 && std::is_same<Tab, LaneTab13>::value) {
+    static_assert(LOGN == 13 && LOGE == 4, "LaneTab13 is the 8192-point table");
+    lane_tw13<LOGNS, FWD>(v, tab);
+  } else if constexpr (LOGNS > 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       int jm = (tid + u * T) & (NS - 1);
@@ -419,7 +496,9 @@ CLFA_HD void dif_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
   constexpr int E = 1 << LOGE, R = 1 << LOGR, U = E / R, T = 1 << (LOGN - LOGE), NS = 1 << LOGNS;
 #pragma unroll
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
-  if constexpr (LOGNS > 0) {
+  if constexpr (LOGNS > 0 && std::is_same<Tab, LaneTab13>::value) {
+    lane_tw13<LOGNS, FWD>(v, tab);
+  } else if constexpr (LOGNS > 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       int jm = (tid + u * T) & (NS - 1);
@@ -578,12 +657,15 @@ CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, cons
         v[u + U / 2 + U * t] = xb[lds_pad(jp + NB * t)];
       }
     }
+    if constexpr (!std::is_same<Tab, LaneTab13>::value) {
 #pragma unroll
-    for (int t = 1; t < R; t++) {
-      v[u + U * t] = cmul_tw<LOGN, FWD>(v[u + U * t], tab, j * t);
-      v[u + U / 2 + U * t] = cmul_tw<LOGN, FWD>(v[u + U / 2 + U * t], tab, jp * t);
+      for (int t = 1; t < R; t++) {
+        v[u + U * t] = cmul_tw<LOGN, FWD>(v[u + U * t], tab, j * t);
+        v[u + U / 2 + U * t] = cmul_tw<LOGN, FWD>(v[u + U / 2 + U * t], tab, jp * t);
+      }
     }
   }
+  if constexpr (std::is_same<Tab, LaneTab13>::value) lane_tw13_paired<FWD>(v, tid, tab);
 #pragma unroll
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
 }
@@ -641,14 +723,18 @@ CLFA_HD void pass_first_paired(cpx (&v)[1 << LOGE], int tid, const cpx (&oi)[(1 
   }
 #pragma unroll
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
+  if constexpr (std::is_same<Tab, LaneTab13>::value) {
+    lane_tw13_paired<FWD>(v, tid, tab);
+  } else {
 #pragma unroll
-  for (int u = 0; u < U / 2; u++) {
-    const int j = tid + u * T;
-    const int jp = j == 0 ? NB / 2 : NB - j;
+    for (int u = 0; u < U / 2; u++) {
+      const int j = tid + u * T;
+      const int jp = j == 0 ? NB / 2 : NB - j;
 #pragma unroll
-    for (int q = 1; q < R; q++) {
-      v[u + U * q] = cmul_tw<LOGN, FWD>(v[u + U * q], tab, j * q);
-      v[u + U / 2 + U * q] = cmul_tw<LOGN, FWD>(v[u + U / 2 + U * q], tab, jp * q);
+      for (int q = 1; q < R; q++) {
+        v[u + U * q] = cmul_tw<LOGN, FWD>(v[u + U * q], tab, j * q);
+        v[u + U / 2 + U * q] = cmul_tw<LOGN, FWD>(v[u + U / 2 + U * q], tab, jp * q);
+      }
     }
   }
 }

@@ -71,11 +71,10 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
                                                               const cpx *__restrict__ w2_g, long batch) {
   using G = LdsGeom<LOGN>;
   constexpr int N = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
-  // twiddles in LDS: half table W_n^k (k < n/2), or for n = 8192 the two-level table
-  // [hi: W_n^(64 j), j < n/64 | lo: W_n^j, j < 64] that keeps the block at 71 KiB
+  // twiddles in LDS: half table W_n^k (k < n/2); n = 8192: the lane-addressed tables of LaneTab13
+  // (fft_device.hpp: 1280 entries, which keeps the block at 78 KiB so that two workgroups share a CU)
   constexpr bool TWO = kLdsTwoLevel(LOGN);
-  constexpr int NHI = N >> kLdsTwoLevelLogLo, NLO = 1 << kLdsTwoLevelLogLo;
-  constexpr int NTAB = TWO ? NHI + NLO : G::HALF;
+  constexpr int NTAB = TWO ? kLane13Lds : G::HALF;
   __shared__ cpx s_tab[NTAB];
   __shared__ cpx s_x[FPW * G::PADN];
 
@@ -83,7 +82,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   const int f = tid / T, t = tid % T;
   for (int i = tid; i < (TWO ? NTAB : N / 2); i += WG) s_tab[i] = tab_g[i];
   cpx *xb = s_x + f * G::PADN;
-  const TwoLevelTab<kLdsTwoLevelLogLo> tab2{s_tab, s_tab + NHI};
+  cpx w13 = mk(1.f, 0.f);
+  if constexpr (TWO) w13 = tab_g[kLane13Lds + t];   // W_8192^t: the lane's own constant
   const cpx *tab1 = s_tab;
 
   // pack / unpack twiddles of this lane's pairs are the same for every transform
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     // prologue and scratch loads in the loop).  Recomputing them costs a few VALU instructions.
     int t = t_invariant;
     asm volatile("" : "+v"(t));
+    const LaneTab13 tab2{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), w13};
     const long b = g * FPW + f;
     const bool active = b < batch;
     cpx *x = data + (active ? b : batch - 1) * (long)N;

@@ -11,9 +11,11 @@ enum FftMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2 };
 // Largest complex length the single-workgroup LDS kernel handles; above it the four-step kernel
 // (two phases, the intermediate in LDS + registers + a small global scratch) takes over.
 constexpr int kLdsMaxLog = 13;
-// complex lengths whose LDS kernel uses the two-level twiddle table [hi (n/64) | lo (64)]
-constexpr int kLdsTwoLevelLogLo = 6;
+// n = 8192 uses lane-addressed twiddle tables instead of the half table (fft_device.hpp, LaneTab13):
+// [W_256^(j t), j, t < 16 | W_4096^(2^k j mod 4096), k < 4, j < 256 | W_8192^t, t < 512]; the first
+// kLane13Lds entries live in LDS
 constexpr bool kLdsTwoLevel(int logn) { return logn >= 13; }
+constexpr int kLane13Lds = 1280, kLane13Size = 1792;
 constexpr int kMaxLog = 16;  // reference int32 index bound, cl_fft.cpp:32
 
 struct FftTables {      // all device pointers, owned by the plan
