@@ -4,6 +4,8 @@
 // per-phase clock stamps.  Results are garbage by construction for every mode but "full".
 #include "../opencl_fft_amd/csrc/fft_resident.hip"
 
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -77,6 +79,38 @@ static void run_split(cpx *data, cpx *slots, cpx *tabs, long batch, int cus, int
   printf("%2d launches of %4ld transforms          %8.3f ms  %6.2f TB/s alg\n", parts, per, ms, batch * 65536.0 * 16 / ms * 1e-9);
 }
 
+// per-launch times of the first launches after an idle period (optionally after `pre` ms of another
+// kernel): how long does the chip take to reach its steady state for this kernel?
+__global__ void k_spin(float *out, int iters) {
+  float a = threadIdx.x * 1e-3f;
+  for (int i = 0; i < iters; i++) a = a * 0.999f + 1e-3f;
+  if (a == 123.456f) out[0] = a;
+}
+static void run_ramp(const char *name, cpx *data, cpx *slots, cpx *tabs, long batch, int cus, int pre_kind, float *sink) {
+  usleep(300000);
+  const int n = 30;
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto &evt : ev) CK(hipEventCreate(&evt));
+  if (pre_kind == 1) {        // ALU-only activity, ~50 ms
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL(k_spin, dim3(cus * 8), dim3(256), 0, 0, sink, 300000);
+  } else if (pre_kind == 2) { // memory activity: 50 launches of the FFT kernel itself
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, (unsigned long long *)nullptr);
+  }
+  CK(hipEventRecord(ev[0]));
+  for (int i = 0; i < n; i++) {
+    hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, (unsigned long long *)nullptr);
+    CK(hipEventRecord(ev[i + 1]));
+  }
+  CK(hipEventSynchronize(ev[n]));
+  printf("%-44s", name);
+  for (int i = 0; i < n; i++) {
+    float ms;
+    CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    printf(" %.3f", ms);
+  }
+  printf("\n");
+}
+
 int main() {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -109,6 +143,49 @@ int main() {
   run<256 | 1 | 16>("rotated, no loads", data, slots, tabs, dbg, batch, cus);
   run<512 | 16>("grid barrier at phase boundaries", data, slots, tabs, dbg, batch, cus);
   run<0>("full (again)", data, slots, tabs, dbg, batch, cus);
-  for (int parts : {1, 2, 4, 8, 16}) run_split(data, slots, tabs, batch, cus, parts);
+  for (int parts : {1, 2, 4}) run_split(data, slots, tabs, batch, cus, parts);
+  float *sink;
+  CK(hipMalloc(&sink, 64));
+  run_ramp("30 launches after 0.3 s idle", data, slots, tabs, batch, cus, 0, sink);
+  run_ramp("... after idle + 50 ms of ALU-only kernels", data, slots, tabs, batch, cus, 1, sink);
+  run_ramp("... after idle + 50 launches of itself", data, slots, tabs, batch, cus, 2, sink);
+  run_ramp("30 launches after 0.3 s idle (again)", data, slots, tabs, batch, cus, 0, sink);
+  {
+    // the same with random data of O(1) magnitude (as bench.py), forward (scaled 1/N) / inverse alternating
+    std::vector<cpx> h(1 << 20);
+    unsigned sd = 1;
+    for (auto &c : h) {
+      sd = sd * 1664525u + 1013904223u;
+      float re = (sd >> 8) / 8388608.f - 1.f;
+      sd = sd * 1664525u + 1013904223u;
+      c = mk(re, (sd >> 8) / 8388608.f - 1.f);
+    }
+    for (long off = 0; off < batch * 65536; off += (1 << 20)) CK(hipMemcpy(data + off, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    std::vector<cpx> tt(1792);
+    // real tables this time (unit-modulus stand-ins would let the values drift)
+    for (int t = 0; t < 16; t++) for (int j = 0; j < 16; j++) tt[16 * t + j] = mk((float)cos(t * j * 2 * M_PI / 256), -(float)sin(t * j * 2 * M_PI / 256));
+    for (int k = 0; k < 256; k++) tt[256 + k] = mk((float)cos(k * 2 * M_PI / 65536), -(float)sin(k * 2 * M_PI / 65536));
+    for (int k = 0; k < 256; k++) tt[512 + k] = mk((float)cos(k * 2 * M_PI / 256), -(float)sin(k * 2 * M_PI / 256));
+    for (int m = 0; m < 4; m++) for (int k = 0; k < 256; k++) { int idx = ((1 << m) * k) & 4095; tt[768 + 256 * m + k] = mk((float)cos(idx * 2 * M_PI / 4096), -(float)sin(idx * 2 * M_PI / 4096)); }
+    CK(hipMemcpy(tabs, tt.data(), 1792 * 8, hipMemcpyHostToDevice));
+    usleep(300000);
+    const int n = 30;
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto &evt : ev) CK(hipEventCreate(&evt));
+    CK(hipEventRecord(ev[0]));
+    for (int i = 0; i < n; i++) {
+      if (i & 1) hipLaunchKernelGGL((k_fft_res16<false, false, 0>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, (unsigned long long *)nullptr);
+      else hipLaunchKernelGGL((k_fft_res16<true, true, 0>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, (unsigned long long *)nullptr);
+      CK(hipEventRecord(ev[i + 1]));
+    }
+    CK(hipEventSynchronize(ev[n]));
+    printf("%-44s", "random data, fwd/inv alternating, after idle");
+    for (int i = 0; i < n; i++) {
+      float ms;
+      CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      printf(" %.3f", ms);
+    }
+    printf("\n");
+  }
   return 0;
 }
