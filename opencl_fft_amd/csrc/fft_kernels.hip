@@ -92,14 +92,40 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   // per lane (fft_device.hpp, pass_last_paired / pass_first_paired): one LDS exchange less
   constexpr bool PAIRED = MODE != MODE_C2C && pair_ok(LOGN, G::LOGE);
   constexpr int RREM = 1 << pass_rem_logr(LOGN, G::LOGE);
-  cpx w2r[NP];
-  if constexpr (MODE != MODE_C2C) {
+  // n = 8192 (M of config 3): the lane's eight pack twiddles W_16384^i, i = t + 512 u and 4096 - i, all
+  // derive from ONE lane constant (g0 = w2[t]) times compile-time constants W_32^u, the partners being
+  // -+i conj(.) — 2 VGPRs across the batch loop instead of 16 (the kernel runs under a 128-VGPR cap)
+  constexpr bool W2LANE = TWO && PAIRED;
+  cpx w2r[W2LANE ? 1 : NP];
+  if constexpr (W2LANE) {
+    w2r[0] = w2_g[t];
+  } else if constexpr (MODE != MODE_C2C) {
 #pragma unroll
     for (int k = 0; k < NP; k++) {
       if constexpr (PAIRED) w2r[k] = w2_g[pair_index<LOGN, G::LOGE>(t, k / RREM, k % RREM)];
       else w2r[k] = w2_g[t + T * k];
     }
   }
+  // pair k = 2 u + q of the lane (pair_index): q = 0 -> w2[t + 512 u], q = 1 -> w2[4096 - (t + 512 u)]
+  // (lane 0, u = 0: w2[2048] = W_8, with the table's sign)
+  auto w2_of = [&](int k, int lane) -> cpx {
+    if constexpr (W2LANE) {
+      constexpr float c32[4] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f};
+      constexpr float s32[4] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f};
+      const int u = k >> 1;
+      cpx w = w2r[0];
+      if (u == 1) w = ctw<FWD>(w, c32[1], s32[1]);
+      if (u == 2) w = ctw<FWD>(w, c32[2], s32[2]);
+      if (u == 3) w = ctw<FWD>(w, c32[3], s32[3]);
+      if (k & 1) {
+        w = FWD ? mk(-w.y, -w.x) : mk(w.y, w.x);   // W^(4096 - i) = -i conj(W^i) (forward sign), +i conj (inverse)
+        if (k == 1 && lane == 0) w = mk(kC8, FWD ? -kC8 : kC8);
+      }
+      return w;
+    } else {
+      return w2r[k];
+    }
+  };
   __syncthreads();
 
   const long groups = (batch + FPW - 1) / FPW;
@@ -140,7 +166,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {
         const int i = pair_index<LOGN, G::LOGE>(t, k / RREM, k % RREM);
-        c2r_pair(v[2 * k], v[2 * k + 1], w2r[k], oi[k], oj[k]);
+        c2r_pair(v[2 * k], v[2 * k + 1], w2_of(k, t), oi[k], oj[k]);
         if (k == 0) {   // lane 0: packed DC/Nyquist, bin N/2 copied through (selects, not a branch)
           const bool z = i == 0;
           oi[0] = mk(z ? v[0].x + v[0].y : oi[0].x, z ? v[0].x - v[0].y : oi[0].y);
@@ -195,7 +221,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       pairs_visit<LOGN, G::LOGE>(v, t, [&](int k, int i, cpx ci, cpx cj) {
         const int j = i == 0 ? N / 2 : N - i;
         cpx oi, oj;
-        r2c_pair(ci, cj, w2r[k], oi, oj);
+        r2c_pair(ci, cj, w2_of(k, t), oi, oj);
         if (k == 0 && i == 0) {   // packed DC/Nyquist; bin N/2 copied through
           oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
           oj = cj;
