@@ -248,6 +248,9 @@ struct clfa_fft {
   // n > 65536 (extension): n = N1 x N2; `tabs` then belongs to the N2-point row transform
   BigGeom big{};
   DevBuf bigtabs, scratch2;
+  // n = 16384 on the one-workgroup-per-CU LDS kernel (packed real size 32768 always: the pair maps are fused
+  // there; complex plans when CLFA_LDS14 says so — resolved at creation)
+  bool lds14 = false;
 };
 
 struct clfa_pconv {
@@ -405,16 +408,25 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     size_t per = sizeof(cpx) * (size_t)n, cap = (size_t)256 << 20;
     if ((e = p->scratch.ensure(per * (cap / per > 0 ? cap / per : 1)))) return e;
   }
-  if (rowlog <= kLdsMaxLog) {
+  if (p->logn == kLds14Log) {
+    const char *sw = getenv("CLFA_LDS14");   // tuning switch, read once: complex n = 16384 on the LDS kernel
+    p->lds14 = real || (sw ? atoi(sw) != 0 : kLds14Complex);
+  }
+  if (rowlog <= kLdsMaxLog || p->lds14) {
     if (kLdsTwoLevel(rowlog)) {
-      // n = 8192: lane-addressed tables (internal.hpp, kLane13Size), every value rounded from double
+      // n = 8192 / 16384: lane-addressed tables (internal.hpp, kLane13Size / kLane14Size), every value rounded from double
       h.clear();
       auto w = [&](long k, long n) { h.push_back(mk((float)cos(k * 2 * kPI / n), -(float)sin(k * 2 * kPI / n))); };
       for (int j = 0; j < 16; j++)
         for (int t = 0; t < 16; t++) w(j * t, 256);
       for (int k = 0; k < 4; k++)
         for (int j = 0; j < 256; j++) w(((1 << k) * j) & 4095, 4096);
-      for (int t = 0; t < 512; t++) w(t, 8192);
+      if (rowlog == kLds14Log) {
+        for (int m = 1; m <= 3; m++)
+          for (int t = 0; t < 1024; t++) w(m * t, 16384);
+      } else {
+        for (int t = 0; t < 512; t++) w(t, 8192);
+      }
     } else {
       fill_twiddle(h, rown / 2, rown, 1, -1.f);
     }
@@ -493,7 +505,7 @@ size_t clfa_fft_workspace_bytes(const clfa_fft *p) { return p ? p->scratch.bytes
 const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
   if (p->logn > kMaxLog) return "k_big_cols";
-  return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
+  return (p->logn <= kLdsMaxLog || p->lds14) ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
 }
 
 int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
@@ -506,7 +518,7 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   HIP_TRY(p->order.use(s));
   cpx *d = (cpx *)data;
   const bool scale = p->fwd;  // cl_fft.cpp:39-40: forward plans divide by N, inverse plans do not
-  if (p->logn <= kLdsMaxLog) {
+  if (p->logn <= kLdsMaxLog || p->lds14) {
     int mode = !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R);
     HIP_TRY(launch_fft_lds(p->logn, p->fwd, mode, scale, d, p->tabs, batch, p->di, s));
     return CLFA_SUCCESS;

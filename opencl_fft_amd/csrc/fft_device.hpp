@@ -390,14 +390,80 @@ template <bool FWD> CLFA_HD void lane_tw13_paired(cpx (&v)[16], int tid, const L
   cmulc2<!FWD>(v[14], v[15], v[14], q2, v[15], q3);
 }
 
+// ---- n = 16384: the same idea for the pass structure 16 x 16 x 16 x 4 (16 points per lane, 1024 lanes) ----
+//   passes 2 and 3    as for n = 8192 (row16, s256 addressed by tid & 15, tid & 255);
+//   pass 4 (radix 4)  butterfly j = tid + 1024 u (u < 4), element t (1..3): W_16384^(j t) =
+//                     W_16384^(t tid) * W_16^(u t): three lane constants (exact table values) times
+//                     compile-time constants.
+struct LaneTab14 {
+  const cpx *row16;   // LDS: W_256^((tid & 15) t), t = 0..15
+  const cpx *s256;    // LDS: [256 k] = W_4096^(2^k (tid & 255)), k = 0..3
+  cpx w1, w2, w3;     // W_16384^(tid), ^(2 tid), ^(3 tid) (forward sign)
+};
+template <class Tab> struct is_lane_tab : std::false_type {};
+template <> struct is_lane_tab<LaneTab13> : std::true_type {};
+template <> struct is_lane_tab<LaneTab14> : std::true_type {};
+// cos / sin(2 pi k / 16), k = 0..9
+constexpr float kC16u[10] = {1.0f, 0.92387953251128675613f, 0.70710678118654752440f, 0.38268343236508977173f, 0.0f,
+                             -0.38268343236508977173f, -0.70710678118654752440f, -0.92387953251128675613f, -1.0f,
+                             -0.92387953251128675613f};
+constexpr float kS16u[10] = {0.0f, 0.38268343236508977173f, 0.70710678118654752440f, 0.92387953251128675613f, 1.0f,
+                             0.92387953251128675613f, 0.70710678118654752440f, 0.38268343236508977173f, 0.0f,
+                             -0.38268343236508977173f};
+template <int LOGNS, bool FWD> CLFA_HD void lane_tw14(cpx (&v)[16], const LaneTab14 &tab) {
+  if constexpr (LOGNS == 4 || LOGNS == 8) {
+    lane_tw13<LOGNS, FWD>(v, LaneTab13{tab.row16, tab.s256, tab.w1});
+  } else {
+    static_assert(LOGNS == 12, "passes of the 16384-point transform");
+    // element u + 4 t: (v * W^(t tid)) * W_16^(u t)
+    cmulc2<!FWD>(v[4], v[5], v[4], tab.w1, v[5], tab.w1);
+    cmulc2<!FWD>(v[6], v[7], v[6], tab.w1, v[7], tab.w1);
+    cmulc2<!FWD>(v[8], v[9], v[8], tab.w2, v[9], tab.w2);
+    cmulc2<!FWD>(v[10], v[11], v[10], tab.w2, v[11], tab.w2);
+    cmulc2<!FWD>(v[12], v[13], v[12], tab.w3, v[13], tab.w3);
+    cmulc2<!FWD>(v[14], v[15], v[14], tab.w3, v[15], tab.w3);
+    ctw2<FWD>(v[5], kC16u[1], kS16u[1], v[6], kC16u[2], kS16u[2]);     // u t = 1, 2
+    ctw2<FWD>(v[7], kC16u[3], kS16u[3], v[9], kC16u[2], kS16u[2]);     // 3, 2
+    ctw2<FWD>(v[10], kC16u[4], kS16u[4], v[11], kC16u[6], kS16u[6]);   // 4, 6
+    ctw2<FWD>(v[13], kC16u[3], kS16u[3], v[14], kC16u[6], kS16u[6]);   // 3, 6
+    v[15] = ctw<FWD>(v[15], kC16u[9], kS16u[9]);                       // 9
+  }
+}
+// paired radix-4 pass (pass_last_paired / pass_first_paired, NB = 4096): slot u + 4 t (u = 0, 1) belongs to
+// butterfly j = tid + 1024 u (twiddle W^(j t)), slot u + 2 + 4 t to its partner NB - j: W^((4096 - j) t) =
+// (-i)^t conj(W^(j t)); lane 0's u = 0 pairs butterflies 0 and NB / 2 = 2048 (W^(2048 t) = W_8^t)
+template <bool FWD> CLFA_HD void lane_tw14_paired(cpx (&v)[16], int tid, const LaneTab14 &tab) {
+  const cpx a1 = tab.w1, a2 = tab.w2, a3 = tab.w3;                         // u = 0: W^(t tid)
+  const cpx b1 = ctw<true>(tab.w1, kC16u[1], kS16u[1]), b2 = ctw<true>(tab.w2, kC16u[2], kS16u[2]),
+            b3 = ctw<true>(tab.w3, kC16u[3], kS16u[3]);                      // u = 1: times W_16^t
+  cpx p1 = mk(-a1.y, -a1.x), p2 = mk(-a2.x, a2.y), p3 = mk(a3.y, a3.x);   // partners of u = 0
+  const cpx q1 = mk(-b1.y, -b1.x), q2 = mk(-b2.x, b2.y), q3 = mk(b3.y, b3.x);
+  if (tid == 0) {
+    p1 = mk(kC8, -kC8);
+    p2 = mk(0.f, -1.f);
+    p3 = mk(-kC8, -kC8);
+  }
+  cmulc2<!FWD>(v[4], v[5], v[4], a1, v[5], b1);
+  cmulc2<!FWD>(v[6], v[7], v[6], p1, v[7], q1);
+  cmulc2<!FWD>(v[8], v[9], v[8], a2, v[9], b2);
+  cmulc2<!FWD>(v[10], v[11], v[10], p2, v[11], q2);
+  cmulc2<!FWD>(v[12], v[13], v[12], a3, v[13], b3);
+  cmulc2<!FWD>(v[14], v[15], v[14], p3, v[15], q3);
+}
+// the lane tables' pass twiddles, by table type
+template <int LOGNS, bool FWD> CLFA_HD void lane_tw(cpx (&v)[16], const LaneTab13 &tab) { lane_tw13<LOGNS, FWD>(v, tab); }
+template <int LOGNS, bool FWD> CLFA_HD void lane_tw(cpx (&v)[16], const LaneTab14 &tab) { lane_tw14<LOGNS, FWD>(v, tab); }
+template <bool FWD> CLFA_HD void lane_tw_paired(cpx (&v)[16], int tid, const LaneTab13 &tab) { lane_tw13_paired<FWD>(v, tid, tab); }
+template <bool FWD> CLFA_HD void lane_tw_paired(cpx (&v)[16], int tid, const LaneTab14 &tab) { lane_tw14_paired<FWD>(v, tid, tab); }
+
 // One pass on the registers of lane `tid`: input twiddles then U butterflies.
 template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
 CLFA_HD void pass_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
   constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
   constexpr int E = 1 << LOGE, R = 1 << LOGR, U = E / R, T = 1 << (LOGN - LOGE), NS = 1 << LOGNS;
-  if constexpr (LOGNS > 0 && std::is_same<Tab, LaneTab13>::value) {
-    static_assert(LOGN == 13 && LOGE == 4, "LaneTab13 is the 8192-point table");
-    lane_tw13<LOGNS, FWD>(v, tab);
+  if constexpr (LOGNS > 0 && is_lane_tab<Tab>::value) {
+    static_assert((LOGN == 13 || LOGN == 14) && LOGE == 4, "lane tables exist for 8192 and 16384 points");
+    lane_tw<LOGNS, FWD>(v, tab);
   } else if constexpr (LOGNS > 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -496,8 +562,8 @@ CLFA_HD void dif_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
   constexpr int E = 1 << LOGE, R = 1 << LOGR, U = E / R, T = 1 << (LOGN - LOGE), NS = 1 << LOGNS;
 #pragma unroll
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
-  if constexpr (LOGNS > 0 && std::is_same<Tab, LaneTab13>::value) {
-    lane_tw13<LOGNS, FWD>(v, tab);
+  if constexpr (LOGNS > 0 && is_lane_tab<Tab>::value) {
+    lane_tw<LOGNS, FWD>(v, tab);
   } else if constexpr (LOGNS > 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -657,7 +723,7 @@ CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, cons
         v[u + U / 2 + U * t] = xb[lds_pad(jp + NB * t)];
       }
     }
-    if constexpr (!std::is_same<Tab, LaneTab13>::value) {
+    if constexpr (!is_lane_tab<Tab>::value) {
 #pragma unroll
       for (int t = 1; t < R; t++) {
         v[u + U * t] = cmul_tw<LOGN, FWD>(v[u + U * t], tab, j * t);
@@ -665,7 +731,7 @@ CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, cons
       }
     }
   }
-  if constexpr (std::is_same<Tab, LaneTab13>::value) lane_tw13_paired<FWD>(v, tid, tab);
+  if constexpr (is_lane_tab<Tab>::value) lane_tw_paired<FWD>(v, tid, tab);
 #pragma unroll
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
 }
@@ -723,8 +789,8 @@ CLFA_HD void pass_first_paired(cpx (&v)[1 << LOGE], int tid, const cpx (&oi)[(1 
   }
 #pragma unroll
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
-  if constexpr (std::is_same<Tab, LaneTab13>::value) {
-    lane_tw13_paired<FWD>(v, tid, tab);
+  if constexpr (is_lane_tab<Tab>::value) {
+    lane_tw_paired<FWD>(v, tid, tab);
   } else {
 #pragma unroll
     for (int u = 0; u < U / 2; u++) {

@@ -82,8 +82,13 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   const int f = tid / T, t = tid % T;
   for (int i = tid; i < (TWO ? NTAB : N / 2); i += WG) s_tab[i] = tab_g[i];
   cpx *xb = s_x + f * G::PADN;
-  cpx w13 = mk(1.f, 0.f);
-  if constexpr (TWO) w13 = tab_g[kLane13Lds + t];   // W_8192^t: the lane's own constant
+  // the lane's own twiddle constants: W_8192^t (n = 8192); W_16384^t, ^(2 t), ^(3 t) (n = 16384)
+  cpx wl[LOGN == 14 ? 3 : 1];
+  wl[0] = mk(1.f, 0.f);
+  if constexpr (TWO) {
+#pragma unroll
+    for (int k = 0; k < (LOGN == 14 ? 3 : 1); k++) wl[k] = tab_g[kLane13Lds + k * T + t];
+  }
   const cpx *tab1 = s_tab;
 
   // pack / unpack twiddles of this lane's pairs are the same for every transform
@@ -109,7 +114,26 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   // pair k = 2 u + q of the lane (pair_index): q = 0 -> w2[t + 512 u], q = 1 -> w2[4096 - (t + 512 u)]
   // (lane 0, u = 0: w2[2048] = W_8, with the table's sign)
   auto w2_of = [&](int k, int lane) -> cpx {
-    if constexpr (W2LANE) {
+    if constexpr (W2LANE && LOGN == 14) {
+      // pair k = 4 u + q of the lane (pair_index), j = t + 1024 u: q = 0 -> w2[j], 1 -> w2[j + 4096] = w2[j] W_8,
+      // 2 -> w2[8192 - j] = -+i conj(w2[j]), 3 -> w2[4096 - j] = W_8 conj(w2[j]);  w2[j] = w2[t] W_32^u.
+      // Lane 0, u = 0 holds the pairs i = 0, 4096, 2048, 6144 instead.
+      const int u = k >> 2, q = k & 3;
+      if (u == 1 && q == 1) return ctw<FWD>(w2r[0], 0.55557023301960222474f, 0.83146961230254523708f);   // W_32^5
+      cpx z = w2r[0];
+      if (u == 1) z = ctw<FWD>(z, 0.98078528040323044913f, 0.19509032201612826785f);                     // W_32^1
+      if (q == 0) return z;
+      if (q == 1) return ctw<FWD>(z, kC8, kC8);
+      cpx w;
+      if (q == 2) {
+        w = FWD ? mk(-z.y, -z.x) : mk(z.y, z.x);
+        if (u == 0 && lane == 0) w = mk(kC16, FWD ? -kS16 : kS16);   // w2[2048] = W_16^1
+      } else {
+        w = ctw<FWD>(mk(z.x, -z.y), kC8, kC8);
+        if (u == 0 && lane == 0) w = mk(kS16, FWD ? -kC16 : kC16);   // w2[6144] = W_16^3
+      }
+      return w;
+    } else if constexpr (W2LANE) {
       constexpr float c32[4] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f};
       constexpr float s32[4] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f};
       const int u = k >> 1;
@@ -147,7 +171,10 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     // prologue and scratch loads in the loop).  Recomputing them costs a few VALU instructions.
     int t = t_invariant;
     asm volatile("" : "+v"(t));
-    const LaneTab13 tab2{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), w13};
+    const auto tab2 = [&]() {
+      if constexpr (LOGN == 14) return LaneTab14{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl[0], wl[1], wl[2]};
+      else return LaneTab13{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl[0]};
+    }();
     const long b = g * FPW + f;
     const bool active = b < batch;
     cpx *x = data + (active ? b : batch - 1) * (long)N;
@@ -453,7 +480,7 @@ hipError_t launch_fft_lds(int logn, bool fwd, int mode, bool scale, cpx *data, c
   case L:         \
     return launch_lds_n<L>(fwd, mode, scale, data, t, batch, di, s);
     CLFA_N(1) CLFA_N(2) CLFA_N(3) CLFA_N(4) CLFA_N(5) CLFA_N(6) CLFA_N(7) CLFA_N(8) CLFA_N(9) CLFA_N(10)
-    CLFA_N(11) CLFA_N(12) CLFA_N(13)
+    CLFA_N(11) CLFA_N(12) CLFA_N(13) CLFA_N(14)
 #undef CLFA_N
     default:
       return hipErrorInvalidValue;

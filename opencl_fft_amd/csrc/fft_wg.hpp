@@ -47,7 +47,7 @@ template <int LOGN> struct LdsGeom {
   // n = 8192 is capped at 128 VGPRs so that two 512-lane workgroups share a CU (LDS 71 KiB each thanks
   // to the two-level twiddle table); with packed arithmetic the register prefetch fits under the cap
   // (28 bytes of spill in c2c / r2c) and is worth 5 % (c2c 4.99 -> 5.22 TB/s, interleaved A/B)
-  static constexpr bool PREFETCH = LOGN <= 13;
+  static constexpr bool PREFETCH = LOGN <= 14;
   static constexpr int MIN_WAVES = LOGN >= 13 ? 4 : 1;
   static constexpr int E = 1 << LOGE;
   static constexpr int T = N / E;                       // lanes per transform

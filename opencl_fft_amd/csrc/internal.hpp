@@ -16,6 +16,11 @@ constexpr int kLdsMaxLog = 13;
 // kLane13Lds entries live in LDS
 constexpr bool kLdsTwoLevel(int logn) { return logn >= 13; }
 constexpr int kLane13Lds = 1280, kLane13Size = 1792;
+// n = 16384 (the one-workgroup-per-CU LDS kernel: 1024 lanes, passes 16 x 16 x 16 x 4; it serves the packed real
+// transforms of size 32768 with the pair maps fused, fft_device.hpp LaneTab14): the same LDS part, then
+// [W_16384^t | W_16384^(2 t) | W_16384^(3 t)], t < 1024
+constexpr int kLds14Log = 14, kLane14Size = kLane13Lds + 3 * 1024;
+constexpr bool kLds14Complex = false;   // complex n = 16384: the four-step kernel unless CLFA_LDS14=1 (measured: DESIGN.md)
 constexpr int kMaxLog = 16;  // reference int32 index bound, cl_fft.cpp:32
 
 struct FftTables {      // all device pointers, owned by the plan

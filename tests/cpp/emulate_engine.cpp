@@ -238,6 +238,147 @@ template <int LOGN, int LOGE> static int paired() {
          bad ? "  FAIL" : "");
   return bad != 0;
 }
+
+// ---- lane-addressed twiddle tables (n = 8192: LaneTab13, n = 16384: LaneTab14) -----------------------
+// The chain with every pass's twiddles taken from the lane tables, plain and with the paired remainder
+// pass (forward: pass_last_paired, inverse: pass_first_paired + transposed chain), against the chain on the
+// exact half table.  The table blob is laid out like the host's (clfft_amd.cpp, fft_setup).
+template <int LOGN> struct LaneOf { using type = LaneTab13; };
+template <> struct LaneOf<14> { using type = LaneTab14; };
+template <int LOGN> static std::vector<typename LaneOf<LOGN>::type> make_lane_tabs(std::vector<cpx> &blob) {
+  constexpr int T = (1 << LOGN) / 16;
+  const double PI = 3.141592653589793;
+  blob.clear();
+  auto w = [&](long k, long n) { blob.push_back(mk((float)cos(k * 2 * PI / n), -(float)sin(k * 2 * PI / n))); };
+  for (int j = 0; j < 16; j++)
+    for (int t = 0; t < 16; t++) w(j * t, 256);
+  for (int k = 0; k < 4; k++)
+    for (int j = 0; j < 256; j++) w(((1 << k) * j) & 4095, 4096);
+  if (LOGN == 14) {
+    for (int m = 1; m <= 3; m++)
+      for (int t = 0; t < 1024; t++) w(m * t, 16384);
+  } else {
+    for (int t = 0; t < 512; t++) w(t, 8192);
+  }
+  std::vector<typename LaneOf<LOGN>::type> tabs(T);
+  for (int t = 0; t < T; t++) {
+    if constexpr (LOGN == 14) tabs[t] = LaneTab14{&blob[16 * (t & 15)], &blob[256 + (t & 255)], blob[1280 + t], blob[1280 + 1024 + t], blob[1280 + 2048 + t]};
+    else tabs[t] = LaneTab13{&blob[16 * (t & 15)], &blob[256 + (t & 255)], blob[1280 + t]};
+  }
+  return tabs;
+}
+template <int LOGN, int LOGNS, bool FWD, bool PAIRLAST, class LT>
+static void run_lane(std::vector<cpx> &regs, const std::vector<LT> &tabs, std::vector<cpx> &lds) {
+  constexpr int LOGE = 4, E = 16, T = 1 << (LOGN - LOGE);
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS), NEXT = LOGNS + LOGR;
+  for (int tid = 0; tid < T; tid++)
+    pass_compute<LOGN, LOGE, LOGNS, FWD>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, tabs[tid]);
+  if constexpr (NEXT < LOGN) {
+    for (int tid = 0; tid < T; tid++)
+      pass_scatter_padded<LOGN, LOGE, LOGNS>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+    if constexpr (PAIRLAST && NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN) {
+      for (int tid = 0; tid < T; tid++)
+        pass_last_paired<LOGN, LOGE, FWD>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, tabs[tid], lds.data());
+    } else {
+      for (int tid = 0; tid < T; tid++)
+        pass_gather_padded<LOGN, LOGE>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+      run_lane<LOGN, NEXT, FWD, PAIRLAST>(regs, tabs, lds);
+    }
+  }
+}
+template <int LOGN, int LOGNS, class LT>
+static void run_lane_dif_inv(std::vector<cpx> &regs, const std::vector<LT> &tabs, std::vector<cpx> &lds) {
+  constexpr int LOGE = 4, E = 16, T = 1 << (LOGN - LOGE);
+  for (int tid = 0; tid < T; tid++) {
+    auto &v = *reinterpret_cast<cpx(*)[E]>(&regs[tid * E]);
+    dif_gather_padded<LOGN, LOGE, LOGNS>(v, tid, lds.data());
+    dif_compute<LOGN, LOGE, LOGNS, false>(v, tid, tabs[tid]);
+  }
+  if constexpr (LOGNS > 0) {
+    for (int tid = 0; tid < T; tid++)
+      dif_scatter_padded<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+    run_lane_dif_inv<LOGN, LOGNS - LOGE>(regs, tabs, lds);
+  }
+}
+static double rel_l2(const std::vector<cpx> &a, const std::vector<cpx> &b) {
+  double num = 0, den = 0;
+  for (size_t i = 0; i < a.size(); i++) {
+    num += (double)(a[i].x - b[i].x) * (a[i].x - b[i].x) + (double)(a[i].y - b[i].y) * (a[i].y - b[i].y);
+    den += (double)b[i].x * b[i].x + (double)b[i].y * b[i].y;
+  }
+  return sqrt(num / den);
+}
+template <int LOGN> static int lane_tables() {
+  constexpr int LOGE = 4, n = 1 << LOGN, E = 16, T = n / E, R = 1 << pass_rem_logr(LOGN, LOGE), U = E / R;
+  std::vector<cpx> blob, x(n), half(n / 2), regs(n), ref(n), lds(lds_padded_size(n));
+  auto tabs = make_lane_tabs<LOGN>(blob);
+  unsigned s = 9001u + LOGN;
+  for (auto &c : x) {
+    s = s * 1664525u + 1013904223u; c.x = (float)(s >> 8) / 8388608.0f - 1.0f;
+    s = s * 1664525u + 1013904223u; c.y = (float)(s >> 8) / 8388608.0f - 1.0f;
+  }
+  const double PI = 3.141592653589793;
+  for (int i = 0; i < n / 2; i++) half[i] = mk((float)cos(i * 2 * PI / n), -(float)sin(i * 2 * PI / n));
+  int bad = 0;
+  auto load = [&](std::vector<cpx> &r, const std::vector<cpx> &src) {
+    for (int tid = 0; tid < T; tid++)
+      for (int e = 0; e < E; e++) r[tid * E + e] = src[tid + T * e];
+  };
+  // plain chain, both directions
+  double e_fwd, e_inv;
+  load(regs, x); load(ref, x);
+  run_lane<LOGN, 0, true, false>(regs, tabs, lds);
+  run<LOGN, LOGE, 0, true>(ref, half, lds);
+  e_fwd = rel_l2(regs, ref);
+  load(regs, x); load(ref, x);
+  run_lane<LOGN, 0, false, false>(regs, tabs, lds);
+  run<LOGN, LOGE, 0, false>(ref, half, lds);
+  e_inv = rel_l2(regs, ref);
+  if (!(e_fwd < 3e-7) || !(e_inv < 3e-7)) bad |= 1;
+  // forward with the paired remainder pass: the pairs it hands out against the natural-order spectrum
+  std::vector<cpx> z(n), got(n);
+  load(ref, x);
+  run<LOGN, LOGE, 0, true>(ref, half, lds);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) z[tid + T * e] = ref[tid * E + e];
+  load(regs, x);
+  run_lane<LOGN, 0, true, true>(regs, tabs, lds);
+  std::vector<int> seen(n, 0);
+  for (int tid = 0; tid < T; tid++)
+    pairs_visit<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, [&](int k, int i, cpx ci, cpx cj) {
+      (void)k;
+      const int j = i == 0 ? n / 2 : n - i;
+      got[i] = ci; got[j] = cj; seen[i]++; seen[j]++;
+    });
+  for (int i = 0; i < n; i++) if (seen[i] != 1) bad |= 2;
+  const double e_pair = rel_l2(got, z);
+  if (!(e_pair < 3e-7)) bad |= 4;
+  // inverse: pass_first_paired fed with natural-order data in pair order + transposed chain
+  load(ref, x);
+  run<LOGN, LOGE, 0, false>(ref, half, lds);
+  std::vector<cpx> wanti(n), goti(n);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) wanti[tid + T * e] = ref[tid * E + e];
+  for (int tid = 0; tid < T; tid++) {
+    cpx oi[E / 2], oj[E / 2];
+    for (int u = 0; u < U / 2; u++)
+      for (int q = 0; q < R; q++) {
+        const int k = u * R + q, i = pair_index<LOGN, LOGE>(tid, u, q), j = i == 0 ? n / 2 : n - i;
+        oi[k] = x[i]; oj[k] = x[j];
+      }
+    pass_first_paired<LOGN, LOGE, false>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, oi, oj, tabs[tid]);
+  }
+  for (int tid = 0; tid < T; tid++)
+    pass_first_paired_scatter<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+  run_lane_dif_inv<LOGN, pass_last_logns(LOGN, LOGE) - LOGE>(regs, tabs, lds);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) goti[tid + T * e] = regs[tid * E + e];
+  const double e_pinv = rel_l2(goti, wanti);
+  if (!(e_pinv < 3e-7)) bad |= 8;
+  printf("n=2^%-2d lane tables vs exact half table: fwd %.3g inv %.3g, paired fwd %.3g, paired inv (transposed chain) %.3g%s\n",
+         LOGN, e_fwd, e_inv, e_pair, e_pinv, bad ? "  FAIL" : "");
+  return bad != 0;
+}
 template <int LOGN, int LOGE> static void both() {
   double a = check<LOGN, LOGE, true>(), b = check<LOGN, LOGE, false>();
   printf("n=2^%-2d E=%-2d relL2 fwd %.3g inv %.3g\n", LOGN, 1 << LOGE, a, b);
@@ -252,6 +393,8 @@ int main() {
   g_fail |= two_level<13, 5, 6, true>() | two_level<13, 5, 6, false>() | two_level<12, 4, 6, true>();
   g_fail |= paired<5, 4>() | paired<6, 4>() | paired<7, 4>() | paired<9, 4>() | paired<10, 4>() | paired<11, 4>() |
             paired<13, 4>() | paired<4, 3>() | paired<5, 3>() | paired<7, 3>();
+  g_fail |= paired<14, 4>();
+  g_fail |= lane_tables<13>() | lane_tables<14>();
   puts(g_fail ? "FAIL" : "OK");
   return g_fail;
 }

@@ -16,7 +16,8 @@ def timeit(step, iters=20, warm=4):
 
 print("| n | batch | c2c ms | c2c Gsamples/s | c2c TB/s (16 B/sample) | r2c+c2r (size 2n) TB/s (8 B/real sample) |")
 print("|---|---|---|---|---|---|")
-for logn in range(1, 25):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 24)   # optional range of log2(n)
+for logn in range(lo, hi + 1):
     n = 1 << logn
     batch = max(1, (1 << 27) // n)
     d = torch.rand((batch, n, 2), device="cuda") * 2 - 1

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -119,6 +120,37 @@ __global__ __launch_bounds__(256) void k_seg(char *__restrict__ dst, const char 
           }
         }
       }
+    }
+  }
+  if (acc == 123.456f) *sink = acc;
+}
+
+
+// GRP adjacent 128-byte column blocks per step, 8 bytes per lane: the accesses of the GRP blocks are
+// interleaved instruction by instruction ((cb, e), (cb + 1, e), ...), so adjacent 128-byte segments are
+// requested back to back by the same wave — does the memory system treat that like one GRP x 128-byte segment?
+template <int GRP, bool NT, int MODE, bool INPLACE, bool FAR = false>
+__global__ __launch_bounds__(256) void k_seg_grp(char *dst, const char *src, long mats, float *sink) {
+  const int l = threadIdx.x, c = l & 15, r0 = l >> 4;
+  float acc = 0;
+  for (long m = blockIdx.x; m < mats; m += gridDim.x) {
+    const char *s = src + m * 524288;
+    char *d = dst + m * 524288;
+    constexpr int GS = FAR ? 2048 / GRP : 128;   // FAR: the GRP blocks of a step are 2048 / GRP bytes apart (not adjacent)
+    for (int cb = 0; cb < 16 / GRP; cb++) {
+      const long off = (long)r0 * 2048 + cb * (FAR ? 128 : 128 * GRP) + c * 8;
+      f2 r[16 * GRP];
+#pragma unroll
+      for (int e = 0; e < 16; e++)
+#pragma unroll
+        for (int g = 0; g < GRP; g++) r[e * GRP + g] = MODE == 2 ? f2{1, 2} : ld8<NT>((const f2 *)(s + off + g * GS + (long)e * 32768));
+#pragma unroll
+      for (int e = 0; e < 16; e++)
+#pragma unroll
+        for (int g = 0; g < GRP; g++) {
+          if (MODE == 1) acc += r[e * GRP + g].x + r[e * GRP + g].y;
+          else st8<NT>((f2 *)(d + off + g * GS + (long)e * 32768), r[e * GRP + g]);
+        }
     }
   }
   if (acc == 123.456f) *sink = acc;
@@ -260,6 +292,32 @@ int main(int argc, char **argv) {
     SEG_ROW(256, false, 1) SEG_ROW(256, false, 2) SEG_ROW(256, true, 1) SEG_ROW(256, true, 2)
     SEG_ROW(512, false, 2) SEG_ROW(512, true, 1) SEG_ROW(512, true, 2)
     SEG_ROW(2048, true, 1) SEG_ROW(2048, true, 2) SEG_ROW(2048, true, 4)
+
+    printf("\n[grp] as seg 128 B / 8 B per lane, but GRP adjacent column blocks per step with their accesses interleaved\n"
+           "      (adjacent 128-byte segments requested back to back); ip = in place (dst = src).\n"
+           "      copy TB/s (read + write counted): 6 rounds of 40 launches per shape, shapes interleaved; min / median / max over rounds\n");
+    {
+      struct Shape { const char *name; std::function<void()> launch; std::vector<float> ms; };
+      std::vector<Shape> shapes;
+#define GRP_SHAPE(GRP, WPC, IP) shapes.push_back({"grp " #GRP " x 128 B, wg/CU " #WPC, [&] { hipLaunchKernelGGL((k_seg_grp<GRP, true, 0, IP>), dim3(cus * WPC), dim3(256), 0, 0, IP ? a : b, a, mats, sink); }, {}});
+      GRP_SHAPE(1, 1, false) GRP_SHAPE(2, 1, false) GRP_SHAPE(4, 1, false) GRP_SHAPE(1, 2, false) GRP_SHAPE(2, 2, false)
+      GRP_SHAPE(1, 1, true) GRP_SHAPE(2, 1, true) GRP_SHAPE(4, 1, true) GRP_SHAPE(1, 2, true) GRP_SHAPE(2, 2, true)
+#define FAR_SHAPE(GRP, WPC, IP) shapes.push_back({"far " #GRP " x 128 B, wg/CU " #WPC " ip=" #IP, [&] { hipLaunchKernelGGL((k_seg_grp<GRP, true, 0, IP, true>), dim3(cus * WPC), dim3(256), 0, 0, IP ? a : b, a, mats, sink); }, {}});
+      FAR_SHAPE(2, 1, true) FAR_SHAPE(4, 1, true) FAR_SHAPE(2, 1, false) FAR_SHAPE(4, 1, false) FAR_SHAPE(8, 1, true)
+      shapes.push_back({"grp 8 x 128 B, wg/CU 1 ip", [&] { hipLaunchKernelGGL((k_seg_grp<8, true, 0, true>), dim3(cus), dim3(256), 0, 0, a, a, mats, sink); }, {}});
+      shapes.push_back({"seg 256 B, 8 B/lane, wg/CU 1", [&] { hipLaunchKernelGGL((k_seg<256, false, true, 0>), dim3(cus), dim3(256), 0, 0, b, a, mats, sink); }, {}});
+      shapes.push_back({"seg 512 B, 16 B/lane, wg/CU 1", [&] { hipLaunchKernelGGL((k_seg<512, true, true, 0>), dim3(cus), dim3(256), 0, 0, b, a, mats, sink); }, {}});
+      for (int round = 0; round < 6; round++)
+        for (auto &sh : shapes) sh.ms.push_back(time_launches(8, 40, sh.launch));
+      const double by = 2.0 * (double)mats * 524288;
+      int idx = 0;
+      for (auto &sh : shapes) {
+        std::vector<float> v = sh.ms;
+        std::sort(v.begin(), v.end());
+        printf("%-32s %s  %6.2f / %6.2f / %6.2f\n", sh.name, (idx >= 5 && idx < 10) ? "ip" : "  ", by / v.back() * 1e-9, by / v[v.size() / 2] * 1e-9, by / v.front() * 1e-9);
+        idx++;
+      }
+    }
     CK(hipFree(a));
     CK(hipFree(b));
   }
