@@ -251,6 +251,7 @@ struct clfa_fft {
   // n = 16384 on the one-workgroup-per-CU LDS kernel (packed real size 32768 always: the pair maps are fused
   // there; complex plans when CLFA_LDS14 says so — resolved at creation)
   bool lds14 = false;
+  bool rlds15 = false;   // packed real size 65536: k_rfft_lds15 (two 16384-point runs per transform, one HBM pass)
 };
 
 struct clfa_pconv {
@@ -412,7 +413,9 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     const char *sw = getenv("CLFA_LDS14");   // tuning switch, read once: complex n = 16384 on the LDS kernel
     p->lds14 = real || (sw ? atoi(sw) != 0 : kLds14Complex);
   }
-  if (rowlog <= kLdsMaxLog || p->lds14) {
+  p->rlds15 = real && p->logn == 15 && !getenv("CLFA_NO_RLDS15");   // tuning switch, read once
+  if (p->rlds15) rowlog = kLds14Log;   // its tables are the 16384-point lane tables
+  if (rowlog <= kLdsMaxLog || p->lds14 || p->rlds15) {
     if (kLdsTwoLevel(rowlog)) {
       // n = 8192 / 16384: lane-addressed tables (internal.hpp, kLane13Size / kLane14Size), every value rounded from double
       h.clear();
@@ -505,6 +508,7 @@ size_t clfa_fft_workspace_bytes(const clfa_fft *p) { return p ? p->scratch.bytes
 const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
   if (p->logn > kMaxLog) return "k_big_cols";
+  if (p->rlds15) return "k_rfft_lds15";
   return (p->logn <= kLdsMaxLog || p->lds14) ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
 }
 
@@ -518,6 +522,10 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   HIP_TRY(p->order.use(s));
   cpx *d = (cpx *)data;
   const bool scale = p->fwd;  // cl_fft.cpp:39-40: forward plans divide by N, inverse plans do not
+  if (p->rlds15) {
+    HIP_TRY(launch_rfft_lds15(p->fwd, d, p->tabs, batch, p->di, s));
+    return CLFA_SUCCESS;
+  }
   if (p->logn <= kLdsMaxLog || p->lds14) {
     int mode = !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R);
     HIP_TRY(launch_fft_lds(p->logn, p->fwd, mode, scale, d, p->tabs, batch, p->di, s));

@@ -828,4 +828,96 @@ template <int LOGN, int LOGE> CLFA_HD void pass_first_paired_scatter(const cpx (
   }
 }
 
+
+// ---- n = 32768 packed real (size 65536) on two 16384-point sub-transforms --------------------------
+// Z (n = 2 M points, M = 16384) splits by decimation in time into A = FFT_M(z[2j]) and B = FFT_M(z[2j+1]):
+// Z[i] = A[i] + W_2M^i B[i], Z[i + M] = A[i] - W_2M^i B[i].  The paired remainder pass leaves A[i], A[M - i],
+// B[i], B[M - i] of eight pairs in one lane, and those four values give Z[i], Z[M + i], Z[M - i], Z[2M - i]:
+// exactly the two pairs (i, 2M - i) and (M - i, M + i) of the reference's pair maps (cl_fft.cpp:178-205).
+// So the whole packed real transform of size 65536 runs through the 16384-point LDS machinery twice, with
+// the radix-2 step and the pair map in registers; the inverse is the transposed network (split, then the
+// transposed chains).  All twiddles W_P^i (P = 2M for the radix-2 step, 4M for the pair maps) of the lane's
+// pair (u, q), i = pair_index<14, 4>(lane, u, q), derive from ONE lane constant c0 = W_P^lane:
+//   j = lane + 1024 u:  q = 0 -> i = j, 1 -> j + 4096, 2 -> 8192 - j, 3 -> 4096 - j
+//   (lane 0, u = 0: i = 0, 4096, 2048, 6144).  S = 0: P = 32768, S = 1: P = 65536.  Sign: c0's (the plan's).
+template <bool FWD, int S> CLFA_HD cpx pair_tw14(cpx c0, int u, int q, int lane) {
+  static_assert(S == 0 || S == 1, "");
+  // W_P^1024 (u = 1), W_P^4096 (q = 1, 3), W_P^2048 / W_P^6144 (lane 0)
+  constexpr float cu = S == 0 ? 0.98078528040323044913f : 0.99518472667219688624f;   // cos(2 pi / 32), cos(2 pi / 64)
+  constexpr float su = S == 0 ? 0.19509032201612826785f : 0.09801714032956060199f;
+  constexpr float cq = S == 0 ? kC8 : kC16, sq = S == 0 ? kC8 : kS16;                 // W_8, W_16
+  constexpr float cuq = S == 0 ? 0.55557023301960222474f : 0.88192126434835502971f;  // W_32^5, W_64^5
+  constexpr float suq = S == 0 ? 0.83146961230254523708f : 0.47139673682599764856f;
+  constexpr float c2k = S == 0 ? kC16 : 0.98078528040323044913f, s2k = S == 0 ? kS16 : 0.19509032201612826785f;   // W_P^2048
+  constexpr float c6k = S == 0 ? kS16 : 0.83146961230254523708f, s6k = S == 0 ? kC16 : 0.55557023301960222474f;   // W_P^6144
+  if (u == 1 && q == 1) return ctw<FWD>(c0, cuq, suq);
+  cpx z = c0;
+  if (u == 1) z = ctw<FWD>(z, cu, su);
+  if (q == 0) return z;
+  if (q == 1) return ctw<FWD>(z, cq, sq);
+  cpx w;
+  if (q == 2) {   // W_P^8192 conj(z): S = 0: -+i conj(z); S = 1: W_8 conj(z)
+    if (S == 0) w = FWD ? mk(-z.y, -z.x) : mk(z.y, z.x);
+    else w = ctw<FWD>(mk(z.x, -z.y), kC8, kC8);
+    if (u == 0 && lane == 0) w = mk(c2k, FWD ? -s2k : s2k);
+  } else {        // W_P^4096 conj(z)
+    w = ctw<FWD>(mk(z.x, -z.y), cq, sq);
+    if (u == 0 && lane == 0) w = mk(c6k, FWD ? -s6k : s6k);
+  }
+  return w;
+}
+constexpr int kM15 = 16384;
+// forward: slot (u, q) of lane `lane`: A[i], A[M - i], B[i], B[M - i] (for i = 0: A[0], A[M / 2], ...) ->
+// st(position, packed spectrum value) x 4.  g0 = W_2M^lane, h0 = W_4M^lane (the r2c table's entries 2 lane, lane).
+template <class St> CLFA_HD void rfft15_fwd_slot(int lane, int u, int q, int i, cpx ai, cpx aj, cpx bi, cpx bj, cpx g0,
+                                                 cpx h0, St st) {
+  const bool first = i == 0;
+  const cpx g = pair_tw14<true, 0>(g0, u, q, lane), h = pair_tw14<true, 1>(h0, u, q, lane);
+  const cpx gp = first ? mk(0.f, -1.f) : mk(-g.x, g.y);       // W_2M^(M - i) = -conj(g);  W_2M^(M / 2) = -i
+  const cpx hp = first ? mk(kC8, -kC8) : mk(-h.y, -h.x);      // W_4M^(M - i) = -i conj(h);  W_4M^(M / 2) = W_8
+  const cpx t1 = cmul(g, bi), t2 = cmul(gp, bj);
+  const cpx zi_a = cadd(ai, t1), zp_a = cadd(aj, t2);
+  cpx zi_b = csub(ai, t1), zp_b = csub(aj, t2);               // Z[M + i], Z[2M - i]
+  if (first) {                                                // i = 0: pair 1 is (Z[0], Z[M]), pair 2 (Z[M/2], Z[3M/2])
+    const cpx s = zi_b;
+    zi_b = zp_b;
+    zp_b = s;
+  }
+  cpx o1a, o1b, o2a, o2b;
+  r2c_pair(zi_a, zp_b, h, o1a, o1b);
+  r2c_pair(zp_a, zi_b, hp, o2a, o2b);
+  if (first) {   // packed DC / Nyquist; bin n / 2 copied through (cl_fft.cpp:178-191 never visits it)
+    o1a = mk((zi_a.x + zi_a.y) * .5f, (zi_a.x - zi_a.y) * .5f);
+    o1b = zp_b;
+  }
+  const int i2 = first ? kM15 / 2 : i;
+  st(i, o1a);
+  st(first ? kM15 : 2 * kM15 - i, o1b);
+  st(kM15 - i2, o2a);
+  st(kM15 + i2, o2b);
+}
+// inverse: the four packed bins of the slot (ld(position)) -> inputs of the two transposed chains:
+// oa / ob = value at sub-position i, pa / pb = value at its partner M - i (pass_first_paired's oi[k] / oj[k])
+template <class Ld> CLFA_HD void rfft15_inv_slot(int lane, int u, int q, int i, cpx g0, cpx h0, Ld ld, cpx &oa, cpx &pa,
+                                                 cpx &ob, cpx &pb) {
+  const bool first = i == 0;
+  const int i2 = first ? kM15 / 2 : i;
+  const cpx x1a = ld(i), x1b = ld(first ? kM15 : 2 * kM15 - i), x2a = ld(kM15 - i2), x2b = ld(kM15 + i2);
+  const cpx g = pair_tw14<false, 0>(g0, u, q, lane), h = pair_tw14<false, 1>(h0, u, q, lane);
+  const cpx gp = first ? mk(0.f, 1.f) : mk(-g.x, g.y);
+  const cpx hp = first ? mk(kC8, kC8) : mk(h.y, h.x);
+  cpx z1a, z1b, z2a, z2b;
+  c2r_pair(x1a, x1b, h, z1a, z1b);
+  c2r_pair(x2a, x2b, hp, z2a, z2b);
+  if (first) {
+    z1a = mk(x1a.x + x1a.y, x1a.x - x1a.y);
+    z1b = z2b;      // Z[3M/2] pairs with Z[M/2] below ...
+    z2b = x1b;      // ... and Z[M] (copied through) with Z[0]
+  }
+  oa = cadd(z1a, z2b);
+  ob = cmul(csub(z1a, z2b), g);
+  pa = cadd(z2a, z1b);
+  pb = cmul(csub(z2a, z1b), gp);
+}
+
 }  // namespace clfa

@@ -22,6 +22,8 @@
 
 namespace clfa {
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------------
 // single-workgroup LDS FFT
 // ---------------------------------------------------------------------------------
@@ -115,24 +117,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   // (lane 0, u = 0: w2[2048] = W_8, with the table's sign)
   auto w2_of = [&](int k, int lane) -> cpx {
     if constexpr (W2LANE && LOGN == 14) {
-      // pair k = 4 u + q of the lane (pair_index), j = t + 1024 u: q = 0 -> w2[j], 1 -> w2[j + 4096] = w2[j] W_8,
-      // 2 -> w2[8192 - j] = -+i conj(w2[j]), 3 -> w2[4096 - j] = W_8 conj(w2[j]);  w2[j] = w2[t] W_32^u.
-      // Lane 0, u = 0 holds the pairs i = 0, 4096, 2048, 6144 instead.
-      const int u = k >> 2, q = k & 3;
-      if (u == 1 && q == 1) return ctw<FWD>(w2r[0], 0.55557023301960222474f, 0.83146961230254523708f);   // W_32^5
-      cpx z = w2r[0];
-      if (u == 1) z = ctw<FWD>(z, 0.98078528040323044913f, 0.19509032201612826785f);                     // W_32^1
-      if (q == 0) return z;
-      if (q == 1) return ctw<FWD>(z, kC8, kC8);
-      cpx w;
-      if (q == 2) {
-        w = FWD ? mk(-z.y, -z.x) : mk(z.y, z.x);
-        if (u == 0 && lane == 0) w = mk(kC16, FWD ? -kS16 : kS16);   // w2[2048] = W_16^1
-      } else {
-        w = ctw<FWD>(mk(z.x, -z.y), kC8, kC8);
-        if (u == 0 && lane == 0) w = mk(kS16, FWD ? -kC16 : kC16);   // w2[6144] = W_16^3
-      }
-      return w;
+      // pair k = 4 u + q of the lane: w2[i] = W_32768^i, i = pair_index(t, u, q), from the lane constant w2[t]
+      return pair_tw14<FWD, 0>(w2r[0], k >> 2, k & 3, lane);
     } else if constexpr (W2LANE) {
       constexpr float c32[4] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f};
       constexpr float s32[4] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f};
@@ -298,6 +284,102 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       lds_fft_load<LOGN, MODE>(v, data + (bn < batch ? bn : batch - 1) * (long)N, t);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// packed real size 65536 (n = 32768 complex): two runs of the 16384-point LDS machinery per transform
+// ---------------------------------------------------------------------------------
+// n = 2 M, M = 16384: the even and odd complex samples z[2j], z[2j+1] — one 16-byte access per lane — go
+// through the 16384-point pass chain one after the other (same 1024 lanes, same exchange buffer); the
+// radix-2 step that joins them and the reference's pair map (cl_fft.cpp:178-205) meet in registers
+// (fft_device.hpp, rfft15_fwd_slot / rfft15_inv_slot): one HBM pass, where the four-step kernel plus the
+// stand-alone pack kernel took two.  The inverse runs the transposed network.
+__device__ __forceinline__ f4v ld_nt16(const cpx *p) { return __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)); }
+__device__ __forceinline__ void st_nt16(cpx *p, f4v v) { __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(p)); }
+
+template <bool FWD, bool SCALE>
+__global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
+                                                        const cpx *__restrict__ w2_g, long batch) {
+  using G = LdsGeom<14>;
+  constexpr int LOGN = 14, LOGE = 4, E = 16, T = 1024, R = 4;
+  __shared__ cpx s_tab[kLane13Lds];
+  __shared__ cpx s_x[G::PADN];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kLane13Lds; i += T) s_tab[i] = tab_g[i];
+  // lane constants kept across the batch loop: W_16384^tid and W_65536^tid only (4 VGPRs; the kernel runs under
+  // the 128-VGPR cap of a 1024-lane workgroup) — W_16384^(2 tid), ^(3 tid) and W_32768^tid are their products
+  const cpx wl0 = tab_g[kLane13Lds + tid];
+  const cpx h0 = w2_g[tid];   // W_65536^tid (the plan's sign)
+  cpx *xb = s_x;
+  __syncthreads();
+#pragma unroll 1
+  for (long b = blockIdx.x; b < batch; b += gridDim.x) {
+    int t = tid;   // opaque per iteration: LDS / global offsets are recomputed, not kept live across the loop
+    asm volatile("" : "+v"(t));
+    const cpx wl1 = cmul(wl0, wl0);
+    const LaneTab14 tab{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0, wl1, cmul(wl0, wl1)};
+    const cpx g0 = cmul(h0, h0);   // W_32768^tid
+    cpx *x = data + b * (long)(2 * kM15);
+    cpx va[E], vb[E];
+    if constexpr (FWD) {
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const f4v q = ld_nt16(x + 2 * (t + T * e));
+        va[e] = mk(q.x, q.y);
+        vb[e] = mk(q.z, q.w);
+      }
+      wg_passes<LOGN, LOGE, 0, true, true>(va, t, tab, xb);
+      wg_passes<LOGN, LOGE, 0, true, true>(vb, t, tab, xb);
+      if constexpr (SCALE) {
+        constexpr float inv = 1.0f / (float)(2 * kM15);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          va[e] = cscale(va[e], inv);
+          vb[e] = cscale(vb[e], inv);
+        }
+      }
+      cpx ai[E / 2], aj[E / 2], bi[E / 2], bj[E / 2];
+      pairs_visit<LOGN, LOGE>(va, t, [&](int k, int, cpx ci, cpx cj) {
+        ai[k] = ci;
+        aj[k] = cj;
+      });
+      pairs_visit<LOGN, LOGE>(vb, t, [&](int k, int, cpx ci, cpx cj) {
+        bi[k] = ci;
+        bj[k] = cj;
+      });
+#pragma unroll
+      for (int k = 0; k < E / 2; k++)
+        rfft15_fwd_slot(t, k / R, k % R, pair_index<LOGN, LOGE>(t, k / R, k % R), ai[k], aj[k], bi[k], bj[k], g0, h0,
+                        [&](int pos, cpx v) { st_nt(x + pos, v); });
+    } else {
+      cpx oa[E / 2], pa[E / 2], ob[E / 2], pb[E / 2];
+#pragma unroll
+      for (int k = 0; k < E / 2; k++)
+        rfft15_inv_slot(t, k / R, k % R, pair_index<LOGN, LOGE>(t, k / R, k % R), g0, h0,
+                        [&](int pos) { return ld_nt(x + pos); }, oa[k], pa[k], ob[k], pb[k]);
+      constexpr int L1 = pass_last_logns(LOGN, LOGE) - LOGE;
+      pass_first_paired<LOGN, LOGE, false>(va, t, oa, pa, tab);
+      __syncthreads();
+      pass_first_paired_scatter<LOGN, LOGE>(va, t, xb);
+      __syncthreads();
+      wg_passes_dif_after<LOGN, LOGE, L1, false>(va, t, tab, xb);
+      pass_first_paired<LOGN, LOGE, false>(vb, t, ob, pb, tab);
+      __syncthreads();
+      pass_first_paired_scatter<LOGN, LOGE>(vb, t, xb);
+      __syncthreads();
+      wg_passes_dif_after<LOGN, LOGE, L1, false>(vb, t, tab, xb);
+#pragma unroll
+      for (int e = 0; e < E; e++) st_nt16(x + 2 * (t + T * e), f4v{va[e].x, va[e].y, vb[e].x, vb[e].y});
+    }
+  }
+}
+
+hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  const int grid = (int)(batch < di.num_cus ? batch : di.num_cus);   // one 1024-lane workgroup per CU
+  if (fwd) hipLaunchKernelGGL((k_rfft_lds15<true, true>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
+  else hipLaunchKernelGGL((k_rfft_lds15<false, false>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------

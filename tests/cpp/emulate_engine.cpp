@@ -4,6 +4,7 @@
 // Built and run by tests/test_engine_emulation.py (no GPU needed).
 #include "../../opencl_fft_amd/csrc/fft_device.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -379,6 +380,110 @@ template <int LOGN> static int lane_tables() {
          LOGN, e_fwd, e_inv, e_pair, e_pinv, bad ? "  FAIL" : "");
   return bad != 0;
 }
+
+// ---- packed real size 65536 on two 16384-point sub-transforms (rfft15_fwd_slot / rfft15_inv_slot) -----
+static int rfft15() {
+  constexpr int LOGN = 14, LOGE = 4, M = 1 << LOGN, n = 2 * M, E = 16, T = M / E, R = 4, U = 4;
+  std::vector<cpx> blob, z(n), half(n / 2), w2f(n), w2i(n), lds(lds_padded_size(n));
+  auto tabs = make_lane_tabs<LOGN>(blob);
+  unsigned s = 31337u;
+  for (auto &c : z) {
+    s = s * 1664525u + 1013904223u; c.x = (float)(s >> 8) / 8388608.0f - 1.0f;
+    s = s * 1664525u + 1013904223u; c.y = (float)(s >> 8) / 8388608.0f - 1.0f;
+  }
+  const double PI = 3.141592653589793;
+  for (int i = 0; i < n / 2; i++) half[i] = mk((float)cos(i * 2 * PI / n), -(float)sin(i * 2 * PI / n));
+  for (int i = 0; i < n; i++) {
+    w2f[i] = mk((float)cos(i * PI / n), -(float)sin(i * PI / n));
+    w2i[i] = mk((float)cos(i * PI / n), (float)sin(i * PI / n));
+  }
+  int bad = 0;
+  // ---- forward: yardstick = 32768-point chain on the exact half table, scaled 1/n, + the reference pair loop
+  std::vector<cpx> regs(n), Z(n), want(n), got(n);
+  {
+    constexpr int T15 = n / E;
+    for (int tid = 0; tid < T15; tid++)
+      for (int e = 0; e < E; e++) regs[tid * E + e] = z[tid + T15 * e];
+    run<15, LOGE, 0, true>(regs, half, lds);
+    for (int tid = 0; tid < T15; tid++)
+      for (int e = 0; e < E; e++) Z[tid + T15 * e] = cscale(regs[tid * E + e], 1.0f / (float)n);
+  }
+  want = Z;
+  want[0] = mk((Z[0].x + Z[0].y) * .5f, (Z[0].x - Z[0].y) * .5f);
+  for (int i = 1; i < n / 2; i++) r2c_pair(Z[i], Z[n - i], w2f[i], want[i], want[n - i]);
+  std::vector<cpx> ra(M), rb(M);
+  for (int tid = 0; tid < T; tid++)
+    for (int e = 0; e < E; e++) {
+      ra[tid * E + e] = z[2 * (tid + T * e)];
+      rb[tid * E + e] = z[2 * (tid + T * e) + 1];
+    }
+  run_lane<LOGN, 0, true, true>(ra, tabs, lds);
+  run_lane<LOGN, 0, true, true>(rb, tabs, lds);
+  std::vector<int> seen(n, 0);
+  for (int tid = 0; tid < T; tid++) {
+    cpx ai[8], aj[8], bi[8], bj[8];
+    int ii[8];
+    pairs_visit<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&ra[tid * E]), tid, [&](int k, int i, cpx ci, cpx cj) {
+      ai[k] = cscale(ci, 1.0f / (float)n); aj[k] = cscale(cj, 1.0f / (float)n); ii[k] = i;
+    });
+    pairs_visit<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&rb[tid * E]), tid, [&](int k, int i, cpx ci, cpx cj) {
+      (void)i; bi[k] = cscale(ci, 1.0f / (float)n); bj[k] = cscale(cj, 1.0f / (float)n);
+    });
+    for (int k = 0; k < 8; k++)
+      rfft15_fwd_slot(tid, k / R, k % R, ii[k], ai[k], aj[k], bi[k], bj[k], w2f[2 * tid], w2f[tid],
+                      [&](int pos, cpx v) { got[pos] = v; seen[pos]++; });
+  }
+  for (int i = 0; i < n; i++) if (seen[i] != 1) bad |= 1;
+  const double e_f = rel_l2(got, want);
+  double mx = 0, mxref = 0;
+  for (int i = 0; i < n; i++) {
+    mx = std::max(mx, (double)std::max(fabsf(got[i].x - want[i].x), fabsf(got[i].y - want[i].y)));
+    mxref = std::max(mxref, (double)std::max(fabsf(want[i].x), fabsf(want[i].y)));
+  }
+  if (!(e_f < 3e-7) || !(mx / mxref < 1e-6)) bad |= 2;
+  // ---- inverse: yardstick = reference pair loop, then the 32768-point inverse chain (unscaled)
+  std::vector<cpx> y = z, wanti(n), goti(n);
+  y[0] = mk(z[0].x + z[0].y, z[0].x - z[0].y);
+  for (int i = 1; i < n / 2; i++) c2r_pair(z[i], z[n - i], w2i[i], y[i], y[n - i]);
+  {
+    constexpr int T15 = n / E;
+    for (int tid = 0; tid < T15; tid++)
+      for (int e = 0; e < E; e++) regs[tid * E + e] = y[tid + T15 * e];
+    run<15, LOGE, 0, false>(regs, half, lds);
+    for (int tid = 0; tid < T15; tid++)
+      for (int e = 0; e < E; e++) wanti[tid + T15 * e] = regs[tid * E + e];
+  }
+  std::fill(seen.begin(), seen.end(), 0);
+  std::vector<cpx> oa(M / 2 * 1), dummy;
+  std::vector<cpx> OA(T * 8), PA(T * 8), OB(T * 8), PB(T * 8);
+  for (int tid = 0; tid < T; tid++)
+    for (int u = 0; u < U / 2; u++)
+      for (int q = 0; q < R; q++) {
+        const int k = u * R + q, i = pair_index<LOGN, LOGE>(tid, u, q);
+        rfft15_inv_slot(tid, u, q, i, w2i[2 * tid], w2i[tid], [&](int pos) { seen[pos]++; return z[pos]; }, OA[tid * 8 + k],
+                        PA[tid * 8 + k], OB[tid * 8 + k], PB[tid * 8 + k]);
+      }
+  for (int i = 0; i < n; i++) if (seen[i] != 1) bad |= 4;
+  for (int half_ = 0; half_ < 2; half_++) {
+    std::vector<cpx> &O = half_ ? OB : OA, &P = half_ ? PB : PA;
+    std::vector<cpx> r(M);
+    for (int tid = 0; tid < T; tid++)
+      pass_first_paired<LOGN, LOGE, false>(*reinterpret_cast<cpx(*)[E]>(&r[tid * E]), tid,
+                                           *reinterpret_cast<const cpx(*)[8]>(&O[tid * 8]),
+                                           *reinterpret_cast<const cpx(*)[8]>(&P[tid * 8]), tabs[tid]);
+    for (int tid = 0; tid < T; tid++)
+      pass_first_paired_scatter<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&r[tid * E]), tid, lds.data());
+    run_lane_dif_inv<LOGN, pass_last_logns(LOGN, LOGE) - LOGE>(r, tabs, lds);
+    for (int tid = 0; tid < T; tid++)
+      for (int e = 0; e < E; e++) goti[2 * (tid + T * e) + half_] = r[tid * E + e];
+  }
+  const double e_i = rel_l2(goti, wanti);
+  if (!(e_i < 3e-7)) bad |= 8;
+  printf("real size 65536 on two 16384-point sub-transforms: forward relL2 %.3g (max %.3g), inverse relL2 %.3g%s\n", e_f,
+         mx / mxref, e_i, bad ? "  FAIL" : "");
+  if (bad) printf("  flags %d\n", bad);
+  return bad != 0;
+}
 template <int LOGN, int LOGE> static void both() {
   double a = check<LOGN, LOGE, true>(), b = check<LOGN, LOGE, false>();
   printf("n=2^%-2d E=%-2d relL2 fwd %.3g inv %.3g\n", LOGN, 1 << LOGE, a, b);
@@ -395,6 +500,7 @@ int main() {
             paired<13, 4>() | paired<4, 3>() | paired<5, 3>() | paired<7, 3>();
   g_fail |= paired<14, 4>();
   g_fail |= lane_tables<13>() | lane_tables<14>();
+  g_fail |= rfft15();
   puts(g_fail ? "FAIL" : "OK");
   return g_fail;
 }
