@@ -896,13 +896,18 @@ template <class St> CLFA_HD void rfft15_fwd_slot(int lane, int u, int q, int i, 
   st(kM15 - i2, o2a);
   st(kM15 + i2, o2b);
 }
-// inverse: the four packed bins of the slot (ld(position)) -> inputs of the two transposed chains:
-// oa / ob = value at sub-position i, pa / pb = value at its partner M - i (pass_first_paired's oi[k] / oj[k])
-template <class Ld> CLFA_HD void rfft15_inv_slot(int lane, int u, int q, int i, cpx g0, cpx h0, Ld ld, cpx &oa, cpx &pa,
-                                                 cpx &ob, cpx &pb) {
+// positions of the slot's four packed bins: pair (i, 2M - i) and pair (M - i, M + i); the slot with i = 0 (lane 0's
+// first) holds (0, M) and (M / 2, 3M / 2)
+CLFA_HD int rfft15_pos(int i, int which) {
   const bool first = i == 0;
   const int i2 = first ? kM15 / 2 : i;
-  const cpx x1a = ld(i), x1b = ld(first ? kM15 : 2 * kM15 - i), x2a = ld(kM15 - i2), x2b = ld(kM15 + i2);
+  return which == 0 ? i : which == 1 ? (first ? kM15 : 2 * kM15 - i) : which == 2 ? kM15 - i2 : kM15 + i2;
+}
+// inverse: the four packed bins of the slot (x1a .. x2b at rfft15_pos(i, 0 .. 3)) -> inputs of the two transposed
+// chains: oa / ob = value at sub-position i, pa / pb = value at its partner M - i (pass_first_paired's oi[k] / oj[k])
+CLFA_HD void rfft15_inv_slot(int lane, int u, int q, int i, cpx g0, cpx h0, cpx x1a, cpx x1b, cpx x2a, cpx x2b, cpx &oa,
+                             cpx &pa, cpx &ob, cpx &pb) {
+  const bool first = i == 0;
   const cpx g = pair_tw14<false, 0>(g0, u, q, lane), h = pair_tw14<false, 1>(h0, u, q, lane);
   const cpx gp = first ? mk(0.f, 1.f) : mk(-g.x, g.y);
   const cpx hp = first ? mk(kC8, kC8) : mk(h.y, h.x);

@@ -348,15 +348,19 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
         bj[k] = cj;
       });
 #pragma unroll
-      for (int k = 0; k < E / 2; k++)
+      for (int k = 0; k < E / 2; k++) {
         rfft15_fwd_slot(t, k / R, k % R, pair_index<LOGN, LOGE>(t, k / R, k % R), ai[k], aj[k], bi[k], bj[k], g0, h0,
                         [&](int pos, cpx v) { st_nt(x + pos, v); });
+        __builtin_amdgcn_sched_barrier(0);   // slot by slot: hoisted, the eight slots' twiddles spill
+      }
     } else {
       cpx oa[E / 2], pa[E / 2], ob[E / 2], pb[E / 2];
 #pragma unroll
-      for (int k = 0; k < E / 2; k++)
-        rfft15_inv_slot(t, k / R, k % R, pair_index<LOGN, LOGE>(t, k / R, k % R), g0, h0,
-                        [&](int pos) { return ld_nt(x + pos); }, oa[k], pa[k], ob[k], pb[k]);
+      for (int k = 0; k < E / 2; k++) {   // (left to the scheduler: with the loads fenced off first the prologue spills more)
+        const int i = pair_index<LOGN, LOGE>(t, k / R, k % R);
+        rfft15_inv_slot(t, k / R, k % R, i, g0, h0, ld_nt(x + rfft15_pos(i, 0)), ld_nt(x + rfft15_pos(i, 1)),
+                        ld_nt(x + rfft15_pos(i, 2)), ld_nt(x + rfft15_pos(i, 3)), oa[k], pa[k], ob[k], pb[k]);
+      }
       constexpr int L1 = pass_last_logns(LOGN, LOGE) - LOGE;
       pass_first_paired<LOGN, LOGE, false>(va, t, oa, pa, tab);
       __syncthreads();

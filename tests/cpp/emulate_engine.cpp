@@ -460,8 +460,14 @@ static int rfft15() {
     for (int u = 0; u < U / 2; u++)
       for (int q = 0; q < R; q++) {
         const int k = u * R + q, i = pair_index<LOGN, LOGE>(tid, u, q);
-        rfft15_inv_slot(tid, u, q, i, w2i[2 * tid], w2i[tid], [&](int pos) { seen[pos]++; return z[pos]; }, OA[tid * 8 + k],
-                        PA[tid * 8 + k], OB[tid * 8 + k], PB[tid * 8 + k]);
+        cpx in[4];
+        for (int w = 0; w < 4; w++) {
+          const int pos = rfft15_pos(i, w);
+          seen[pos]++;
+          in[w] = z[pos];
+        }
+        rfft15_inv_slot(tid, u, q, i, w2i[2 * tid], w2i[tid], in[0], in[1], in[2], in[3], OA[tid * 8 + k], PA[tid * 8 + k],
+                        OB[tid * 8 + k], PB[tid * 8 + k]);
       }
   for (int i = 0; i < n; i++) if (seen[i] != 1) bad |= 4;
   for (int half_ = 0; half_ < 2; half_++) {
