@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="override batches / channels per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bandwidth", action="store_true", help="skip the device copy/read/write yardsticks")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the full-size property check before the warm-up")
     ap.add_argument("--series-out", default="", help="write the per-launch times (ms) of the timed region to this file")
     return ap.parse_args()
 
@@ -161,6 +162,40 @@ def main():
         kernel, tkey = "k_pconv_fused", "pconv1024x94"
         metric, unit = "channel-samples/s for partitioned convolution (x1e9)", "Gsamples/s"
 
+    # Full-size guard BEFORE anything is timed (a broken kernel must not get a number): on the benchmark's own
+    # buffer, at the benchmark's own size — the size-independent properties of the transform: round trip,
+    # Parseval, linearity (c2c); round trip (packed real).  ~15 launch-equivalents of device work; the data are
+    # restored bit for bit afterwards.  (Side effect, stated in DESIGN.md section 5: the chip's ~20 ms start-up
+    # clock ramp is over when the W warm-up steps begin.)
+    if a.workload in ("c2c", "rfft") and not a.no_selfcheck:
+        with torch.cuda.stream(stream):
+            x0 = data.clone()
+            e0 = (x0.double() ** 2).sum()
+            assert plans[0].exec_device(data, batch, stream.cuda_stream) == 0          # forward (scaled 1/n)
+            checks = {}
+            if a.workload == "c2c":
+                fx = data.clone()
+                checks["parseval_rel"] = abs(float(((fx.double() ** 2).sum() * n / e0).item()) - 1.0)
+            assert plans[1].exec_device(data, batch, stream.cuda_stream) == 0          # inverse
+            checks["roundtrip_max_abs"] = float((data - x0).abs().max().item())
+            if a.workload == "c2c":
+                y = torch.rand(data.shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1
+                z = 0.5 * x0 + y
+                assert plans[0].exec_device(y, batch, stream.cuda_stream) == 0
+                assert plans[0].exec_device(z, batch, stream.cuda_stream) == 0
+                z -= 0.5 * fx + y
+                checks["linearity_max_abs"] = float(z.abs().max().item())
+                checks["linearity_ref_max"] = float(fx.abs().max().item())
+                del fx, y, z
+            data.copy_(x0)
+            del x0
+            stream.synchronize()
+        assert checks["roundtrip_max_abs"] < 2e-5, checks          # |x| <= 1, float32, log2(n) = 16 stages each way
+        if a.workload == "c2c":
+            assert checks["parseval_rel"] < 1e-5, checks
+            assert checks["linearity_max_abs"] < 1e-5 * max(checks["linearity_ref_max"], 1e-30) + 1e-7, checks
+        extra["full_size_selfcheck"] = checks
+
     with torch.cuda.stream(stream):
         for k in range(W):
             assert step(k) == 0
@@ -168,12 +203,19 @@ def main():
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+        # HIP events on the launch stream bracket the K launches: roofline.achieved divides by their mean.
+        # One event pair for the whole region — an event after EVERY launch (--series-out) keeps the stream
+        # from running launches back to back and costs a 0.2 ms kernel 5-8 % (a 0.9 ms one 1-2 %).
+        series = bool(a.series_out)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1 if series else 2)]
         t0 = time.perf_counter()
         ev[0].record(stream)
         for k in range(K):
             rc = step(k)
-            ev[k + 1].record(stream)
+            if series:
+                ev[k + 1].record(stream)
+        if not series:
+            ev[1].record(stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         barrier()
@@ -182,12 +224,11 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
-    per_launch_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(K)]
-    fwd_ms = per_launch_ms[0::2] if a.workload != "pconv" else per_launch_ms
-    avg_ms = sum(fwd_ms) / len(fwd_ms)
-    if a.workload != "pconv" and K > 1:
-        inv_ms = per_launch_ms[1::2]
-        extra["launch_ms"] = {"fwd_avg": avg_ms, "fwd_min": min(fwd_ms), "fwd_max": max(fwd_ms),
+    avg_ms = ev[0].elapsed_time(ev[-1]) / K          # mean launch duration over the timed region (both directions)
+    per_launch_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(K)] if series else []
+    if series and a.workload != "pconv" and K > 1:
+        fwd_ms, inv_ms = per_launch_ms[0::2], per_launch_ms[1::2]
+        extra["launch_ms"] = {"fwd_avg": sum(fwd_ms) / len(fwd_ms), "fwd_min": min(fwd_ms), "fwd_max": max(fwd_ms),
                               "inv_avg": sum(inv_ms) / len(inv_ms), "inv_min": min(inv_ms), "inv_max": max(inv_ms)}
 
     # The yardsticks the roofline fraction is read against: sustained device

@@ -82,6 +82,15 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
 
   const int tid = threadIdx.x;
   const int f = tid / T, t = tid % T;
+  const long groups = (batch + FPW - 1) / FPW;
+  long g = blockIdx.x;
+  if (g >= groups) return;   // whole workgroup (uniform): launchers never over-provision the grid
+  // the first transform's loads are issued before anything else: they fly while the tables are filled
+  cpx v[E], vn[E];
+  {
+    const long b = g * FPW + f;
+    lds_fft_load<LOGN, MODE>(v, data + (b < batch ? b : batch - 1) * (long)N, t);
+  }
   for (int i = tid; i < (TWO ? NTAB : N / 2); i += WG) s_tab[i] = tab_g[i];
   cpx *xb = s_x + f * G::PADN;
   // the lane's own twiddle constants: W_8192^t (n = 8192); W_16384^t, ^(2 t), ^(3 t) (n = 16384)
@@ -137,17 +146,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     }
   };
   __syncthreads();
-
-  const long groups = (batch + FPW - 1) / FPW;
-  long g = blockIdx.x;
-  cpx v[E], vn[E];
-  if (g >= groups) return;   // whole workgroup (uniform): launchers never over-provision the grid
-  {
-    const long b = g * FPW + f;
-    lds_fft_load<LOGN, MODE>(v, data + (b < batch ? b : batch - 1) * (long)N, t);
 #pragma unroll
-    for (int e = 0; e < E; e++) asm volatile("" : "+v"(v[e]));
-  }
+  for (int e = 0; e < E; e++) asm volatile("" : "+v"(v[e]));
   const int t_invariant = t;
 #pragma unroll 1
   for (; g < groups; g += gridDim.x) {
