@@ -13,7 +13,7 @@ def main(src, tag, key, kernel_substr, root):
     os.makedirs(dst, exist_ok=True)
     for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
-    for f in ("bench_unprofiled.json", "bench_driver_cmdline.json", "series_steps20.txt", "series_steps100.txt", "summary.json"):
+    for f in ("bench_unprofiled.json", "bench_driver_cmdline.json", "series_steps20.txt", "series_steps100.txt", "series_cold_start.txt", "summary.json"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "summary.json" else "pmc_summary.json"))
     acc = {}

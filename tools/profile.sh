@@ -8,11 +8,16 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-bandwidth $*"
-# the driver's command line first (20 steps, 5 warm-up, yardsticks included), with its per-launch series
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --series-out "$OUT/series_steps20.txt" $* > "$OUT/bench_driver_cmdline.json" 2> "$OUT/bench_unprofiled.err" || exit 1
+# the driver's command line first (20 steps, 5 warm-up, yardsticks included) ...
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline $* > "$OUT/bench_driver_cmdline.json" 2> "$OUT/bench_unprofiled.err" || exit 1
 echo "== driver command line"; cat "$OUT/bench_driver_cmdline.json"
-python3 bench.py $ARGS --series-out "$OUT/series_steps100.txt" > "$OUT/bench_unprofiled.json" 2>> "$OUT/bench_unprofiled.err" || exit 1
+python3 bench.py $ARGS > "$OUT/bench_unprofiled.json" 2>> "$OUT/bench_unprofiled.err" || exit 1
 echo "== unprofiled"; cat "$OUT/bench_unprofiled.json"
+# ... and the per-launch series of both command lines (an event after every launch: a run of its own), plus a
+# cold start without the full-size guard (the chip's start-up clock ramp)
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bandwidth --series-out "$OUT/series_steps20.txt" $* > /dev/null 2>> "$OUT/bench_unprofiled.err"
+python3 bench.py $ARGS --series-out "$OUT/series_steps100.txt" > /dev/null 2>> "$OUT/bench_unprofiled.err"
+python3 bench.py --steps 60 --warmup 0 --no-cpu-baseline --no-bandwidth --no-selfcheck --series-out "$OUT/series_cold_start.txt" $* > /dev/null 2>> "$OUT/bench_unprofiled.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS > "$OUT/stats.log" 2>&1 || { tail -5 "$OUT/stats.log"; exit 2; }
 echo "== stats done"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
