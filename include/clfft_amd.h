@@ -80,12 +80,15 @@ CLFA_API int clfa_r2c_twiddle_table(int m, int forward, float *out);
 /* ---- complex FFT: cl_fft::Clcfft ------------------------------------------- */
 /* Clcfft::Clcfft(device_id, size, fwd), cl_fft.cpp:44-125.  n = 2^k, 2..65536 is the reference's
  * range (its stage kernel overflows int32 above that, cl_fft.cpp:32); as an extension n up to 2^24
- * is accepted (two passes up to 2^20, three above; 256 MiB of workspace).
+ * is accepted (two passes up to 2^20, three above; 256 MiB of workspace), and so is any length 2..2^22
+ * that is not a power of two (the reference's callers pad those, opcode.cpp:30-35): exact DFT by Bluestein's
+ * algorithm around two power-of-two plans, same scaling conventions.
  * On failure *plan is still a valid handle whose clfa_fft_get_error() reports
  * the setup error (the reference's constructors never throw, cl_fft.h:65). */
 CLFA_API int clfa_cfft_create(clfa_fft **plan, int device, int n, int forward);
 /* Clrfft::Clrfft(device_id, size, fwd), cl_fft.cpp:208-259.  size real points
- * = 2^k, 4..131072 (extension: up to 2^25); the inner complex length is M = size/2 (cl_fft.cpp:210). */
+ * = 2^k, 4..131072 (extension: up to 2^25, and multiples of 4 that are not powers of two up to 2^23);
+ * the inner complex length is M = size/2 (cl_fft.cpp:210). */
 CLFA_API int clfa_rfft_create(clfa_fft **plan, int device, int size, int forward);
 /* Clcfft::~Clcfft / Clrfft::~Clrfft, cl_fft.cpp:127-136, 261-265 */
 CLFA_API void clfa_fft_destroy(clfa_fft *plan);

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "internal.hpp"
@@ -252,6 +253,10 @@ struct clfa_fft {
   // there; complex plans when CLFA_LDS14 says so — resolved at creation)
   bool lds14 = false;
   bool rlds15 = false;   // packed real size 65536: k_rfft_lds15 (two 16384-point runs per transform, one HBM pass)
+  // any other length (extension): Bluestein around two power-of-two plans of length blue_m
+  int blue_m = 0;
+  clfa_fft *blue_f = nullptr, *blue_i = nullptr;
+  DevBuf blue_w, blue_b, blue_work;
 };
 
 struct clfa_pconv {
@@ -375,16 +380,95 @@ int clfa_r2c_twiddle_table(int m, int forward, float *out) {
 // FFT plans
 // ---------------------------------------------------------------------------------
 
+// host double-precision radix-2 transform (unscaled, forward sign), for the Bluestein filter table
+static void host_fft(std::vector<double> &re, std::vector<double> &im) {
+  const size_t n = re.size();
+  for (size_t i = 1, j = 0; i < n; i++) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      std::swap(re[i], re[j]);
+      std::swap(im[i], im[j]);
+    }
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t h = len / 2;
+    std::vector<double> c(h), sn(h);
+    for (size_t k = 0; k < h; k++) {
+      c[k] = cos(2 * kPI * (double)k / (double)len);
+      sn[k] = -sin(2 * kPI * (double)k / (double)len);
+    }
+    for (size_t i = 0; i < n; i += len)
+      for (size_t k = 0; k < h; k++) {
+        const double xr = re[i + k + h] * c[k] - im[i + k + h] * sn[k], xi = re[i + k + h] * sn[k] + im[i + k + h] * c[k];
+        re[i + k + h] = re[i + k] - xr;
+        im[i + k + h] = im[i + k] - xi;
+        re[i + k] += xr;
+        im[i + k] += xi;
+      }
+  }
+}
+
+// any length that is not a power of two (extension): chirp w[j] = exp(-+ i pi j^2 / n) (j^2 reduced mod 2 n
+// in integers, then double), filter B = DFT_m(conj(w) wrapped round m) in double, two m-point sub-plans
+static int blue_setup(clfa_fft *p, int device, int n, bool real, bool fwd) {
+  if (real && (n & 1)) {
+    snprintf(p->log, sizeof(p->log), "real sizes that are not powers of two must be multiples of 4 (got %d)", 2 * n);
+    return CLFA_INVALID_VALUE;
+  }
+  int e = device_info(device, p->di);
+  if (e) return e;
+  ENTER_DEVICE(device);
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  p->logn = -1;
+  int m = 1;
+  while (m < 2 * n - 1) m <<= 1;
+  p->blue_m = m;
+  const double sgn = fwd ? -1.0 : 1.0;
+  std::vector<cpx> w(n), bt(m);
+  std::vector<double> br(m, 0.0), bi(m, 0.0);
+  for (int j = 0; j < n; j++) {
+    const long long q = ((long long)j * j) % (2LL * n);
+    const double a = kPI * (double)q / (double)n;
+    w[j] = mk((float)cos(a), (float)(sgn * sin(a)));
+    br[j] = cos(a);
+    bi[j] = -sgn * sin(a);              // conj(w)
+    if (j) {
+      br[m - j] = br[j];
+      bi[m - j] = bi[j];
+    }
+  }
+  host_fft(br, bi);
+  for (int k = 0; k < m; k++) bt[k] = mk((float)br[k], (float)bi[k]);
+  if ((e = upload(p->blue_w, w.data(), sizeof(cpx) * n))) return e;
+  if ((e = upload(p->blue_b, bt.data(), sizeof(cpx) * m))) return e;
+  if ((e = clfa_cfft_create(&p->blue_f, device, m, 1))) return e;
+  if ((e = clfa_cfft_create(&p->blue_i, device, m, 0))) return e;
+  // workspace: as many m-point rows as fit 256 MiB (at least one); exec walks the batch in such chunks
+  const size_t per = sizeof(cpx) * (size_t)m, cap = (size_t)256 << 20;
+  if ((e = p->blue_work.ensure(per * (cap / per > 0 ? cap / per : 1)))) return e;
+  if (real) {
+    std::vector<cpx> h;
+    fill_w2(h, n, fwd ? -1.f : 1.f);
+    if ((e = upload(p->w2, h.data(), sizeof(cpx) * n))) return e;
+    p->tabs.w2 = (const cpx *)p->w2.p;
+  }
+  return CLFA_SUCCESS;
+}
+
 static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool fwd) {
   p->real = real;
   p->fwd = fwd;
   p->n = n;
   p->size = size;
   p->log[0] = 0;
-  if (!is_pow2(n) || n < 2 || n > (1 << kBigMaxLog)) {
-    snprintf(p->log, sizeof(p->log), "size must be a power of two, complex length 2..%d (got %d)", 1 << kBigMaxLog, n);
+  if (n < 2 || (is_pow2(n) && n > (1 << kBigMaxLog)) || (!is_pow2(n) && n > kBlueMaxN)) {
+    snprintf(p->log, sizeof(p->log), "complex length must be 2..%d (powers of two) or 2..%d (other lengths), got %d",
+             1 << kBigMaxLog, kBlueMaxN, n);
     return CLFA_INVALID_VALUE;
   }
+  if (!is_pow2(n)) return blue_setup(p, device, n, real, fwd);
   p->logn = ilog2(n);
   int e = device_info(device, p->di);
   if (e) return e;
@@ -470,9 +554,9 @@ int clfa_rfft_create(clfa_fft **plan, int device, int size, int forward) {
   if (!plan) return CLFA_INVALID_VALUE;
   clfa_fft *p = new (std::nothrow) clfa_fft();
   if (!p) return CLFA_OUT_OF_HOST_MEMORY;
-  if (size < 4 || !is_pow2(size)) {
+  if (size < 4 || (size & 1)) {
     p->log[0] = 0;
-    snprintf(p->log, sizeof(p->log), "real size must be a power of two, 4..%d (got %d)", 2 << kBigMaxLog, size);
+    snprintf(p->log, sizeof(p->log), "real size must be even, 4..%d (got %d)", 2 << kBigMaxLog, size);
     p->err = CLFA_INVALID_VALUE;
   } else {
     p->err = fft_setup(p, device, size / 2, true, size, forward != 0);
@@ -489,6 +573,11 @@ void clfa_fft_destroy(clfa_fft *p) {
     (void)hipStreamSynchronize(p->stream);
     (void)hipStreamDestroy(p->stream);
   }
+  if (p->blue_f) clfa_fft_destroy(p->blue_f);
+  if (p->blue_i) clfa_fft_destroy(p->blue_i);
+  p->blue_w.release();
+  p->blue_b.release();
+  p->blue_work.release();
   p->half.release();
   p->w2.release();
   p->four.release();
@@ -503,11 +592,16 @@ void clfa_fft_destroy(clfa_fft *p) {
 
 int clfa_fft_get_error(const clfa_fft *p) { return p ? p->err : CLFA_INVALID_VALUE; }
 const char *clfa_fft_get_log(const clfa_fft *p) { return p ? p->log : ""; }
-size_t clfa_fft_workspace_bytes(const clfa_fft *p) { return p ? p->scratch.bytes + p->scratch2.bytes : 0; }
+size_t clfa_fft_workspace_bytes(const clfa_fft *p) {
+  if (!p) return 0;
+  size_t sub = p->blue_f ? clfa_fft_workspace_bytes(p->blue_f) + clfa_fft_workspace_bytes(p->blue_i) : 0;
+  return p->scratch.bytes + p->scratch2.bytes + p->blue_work.bytes + sub;
+}
 
 const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
   if (p->logn > kMaxLog) return "k_big_cols";
+  if (p->blue_m) return "bluestein";
   if (p->rlds15) return "k_rfft_lds15";
   return (p->logn <= kLdsMaxLog || p->lds14) ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
 }
@@ -522,6 +616,25 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   HIP_TRY(p->order.use(s));
   cpx *d = (cpx *)data;
   const bool scale = p->fwd;  // cl_fft.cpp:39-40: forward plans divide by N, inverse plans do not
+  if (p->blue_m) {
+    const int n = p->n, m = p->blue_m;
+    cpx *work = (cpx *)p->blue_work.p;
+    const cpx *w = (const cpx *)p->blue_w.p, *bt = (const cpx *)p->blue_b.p;
+    if (p->real && !p->fwd) HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, n, batch, s));
+    const long cb = (long)(p->blue_work.bytes / (sizeof(cpx) * (size_t)m));
+    for (long b0 = 0; b0 < batch; b0 += cb) {
+      const long nb = batch - b0 < cb ? batch - b0 : cb;
+      cpx *x = d + b0 * (long)n;
+      HIP_TRY(launch_blue_pre(x, w, work, n, m, nb, s));
+      int e = clfa_fft_exec_dev(p->blue_f, work, nb, s);
+      if (e) return e;
+      HIP_TRY(launch_blue_mul(work, bt, m, nb, s));
+      if ((e = clfa_fft_exec_dev(p->blue_i, work, nb, s))) return e;
+      HIP_TRY(launch_blue_post(work, w, x, n, m, scale ? 1.0f / (float)n : 1.0f, nb, s));
+    }
+    if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, n, batch, s));
+    return CLFA_SUCCESS;
+  }
   if (p->rlds15) {
     HIP_TRY(launch_rfft_lds15(p->fwd, d, p->tabs, batch, p->di, s));
     return CLFA_SUCCESS;

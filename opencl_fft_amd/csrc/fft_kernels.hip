@@ -1312,6 +1312,49 @@ hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStr
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// arbitrary lengths (extension): Bluestein's chirp-z over the power-of-two kernels
+// ---------------------------------------------------------------------------------
+// The reference only knows powers of two (its callers pad, opcode.cpp:30-35).  For any other n,
+//   X[k] = w[k] * sum_j (x[j] w[j]) conj(w)[k - j],   w[j] = exp(-+ i pi j^2 / n),
+// a circular convolution of length m = 2^ceil(log2(2n - 1)): pre-multiply and zero-pad into the workspace,
+// m-point forward transform (scaled 1/m), times B = DFT_m(conj(w) wrapped), m-point inverse transform
+// (unscaled), post-multiply (and 1/n for forward plans).  Tables w, B come from the host in double.
+__global__ __launch_bounds__(256) void k_blue_pre(const cpx *__restrict__ x, const cpx *__restrict__ w, cpx *__restrict__ a,
+                                                  int n, int m, long total) {
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long b = g / m;
+    const int j = (int)(g - b * m);
+    a[g] = j < n ? cmul(x[b * n + j], w[j]) : mk(0.f, 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void k_blue_mul(cpx *__restrict__ a, const cpx *__restrict__ bt, int m, long total) {
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < total; g += (long)gridDim.x * 256) a[g] = cmul(a[g], bt[g % m]);
+}
+__global__ __launch_bounds__(256) void k_blue_post(const cpx *__restrict__ a, const cpx *__restrict__ w, cpx *__restrict__ x,
+                                                   int n, int m, float scale, long total) {
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long b = g / n;
+    const int k = (int)(g - b * n);
+    x[g] = cscale(cmul(a[b * m + k], w[k]), scale);
+  }
+}
+hipError_t launch_blue_pre(const cpx *x, const cpx *w, cpx *a, int n, int m, long batch, hipStream_t s) {
+  const long total = batch * m;
+  hipLaunchKernelGGL(k_blue_pre, dim3(grid_for(total)), dim3(256), 0, s, x, w, a, n, m, total);
+  return hipGetLastError();
+}
+hipError_t launch_blue_mul(cpx *a, const cpx *bt, int m, long batch, hipStream_t s) {
+  const long total = batch * m;
+  hipLaunchKernelGGL(k_blue_mul, dim3(grid_for(total)), dim3(256), 0, s, a, bt, m, total);
+  return hipGetLastError();
+}
+hipError_t launch_blue_post(const cpx *a, const cpx *w, cpx *x, int n, int m, float scale, long batch, hipStream_t s) {
+  const long total = batch * n;
+  hipLaunchKernelGGL(k_blue_post, dim3(grid_for(total)), dim3(256), 0, s, a, w, x, n, m, scale, total);
+  return hipGetLastError();
+}
+
 // reference reorder (cl_fft.cpp:24-27): out[k] = in[bitrev(k)].  The table of
 // cl_fft.cpp:96-101 is exactly the log2(n)-bit reversal, computed here with
 // v_bfrev_b32 instead of a table read.

@@ -75,6 +75,13 @@ hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx
 hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
 hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
 
+// arbitrary (non power-of-two) complex lengths, an extension: Bluestein's algorithm around two m-point
+// power-of-two transforms, m >= 2 n - 1 (fft_kernels.hip); n up to kBlueMaxN
+constexpr int kBlueMaxN = 1 << 22;
+hipError_t launch_blue_pre(const cpx *x, const cpx *w, cpx *a, int n, int m, long batch, hipStream_t s);
+hipError_t launch_blue_mul(cpx *a, const cpx *bt, int m, long batch, hipStream_t s);
+hipError_t launch_blue_post(const cpx *a, const cpx *w, cpx *x, int n, int m, float scale, long batch, hipStream_t s);
+
 // reference `reorder` kernel as an op
 hipError_t launch_reorder(cpx *out, const cpx *in, int logn, long batch, hipStream_t s);
 

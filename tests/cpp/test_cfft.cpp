@@ -81,7 +81,7 @@ int main() {
     }
   }
   // error convention: a bad size is reported through get_error(), nothing throws
-  Clcfft wrong(device_ids[DEVID], 1000, true);
+  Clcfft wrong(device_ids[DEVID], 1, true);
   if (wrong.get_error() != CL_INVALID_VALUE || std::string(cl_error_string(wrong.get_error())) != "Invalid value") bad++;
   std::cout << (bad ? "FAIL" : "OK") << std::endl;
   return bad ? 1 : 0;

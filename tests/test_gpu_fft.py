@@ -96,7 +96,7 @@ def test_cfft_empty_batch_and_bad_sizes():
     plan = fa.Clcfft(0, 64, True)
     assert plan.transform(np.zeros((0, 64), np.complex64)) == 0
     assert plan.transform(np.zeros(32, np.complex64)) == -30
-    for n in (0, 1, 3, 1000, 1 << 25):
+    for n in (0, 1, (1 << 22) + 1, 1 << 25):            # (other lengths up to 2^22: Bluestein, below)
         bad = fa.Clcfft(0, n, True)
         assert bad.get_error() == -30 and fa.cl_error_string(bad.get_error()) == "Invalid value"
         assert bad.transform(np.zeros(max(n, 1), np.complex64)) == -30
@@ -217,7 +217,7 @@ def test_rfft_batched_in_place(size, batch):
 
 
 def test_rfft_bad_sizes():
-    for s in (0, 2, 3, 12, 1 << 26):
+    for s in (0, 2, 3, 6, 1 << 26):                      # odd, or not a power of two and not a multiple of 4
         assert fa.Clrfft(0, s, True).get_error() == -30
 
 
@@ -289,6 +289,69 @@ def test_cfft_big_sizes(logn, batch):
     assert_parity(z, want.astype(np.complex64), what="inv 2^%d" % logn)
     assert i.transform(y) == 0                       # round trip
     assert_parity(y, x, what="round trip 2^%d" % logn)
+
+
+
+# ---- lengths that are not powers of two (extension) -----------------------
+# The reference itself only runs powers of two (its callers pad, opcode.cpp:30-35); Bluestein's algorithm
+# around two power-of-two plans gives the exact DFT of any length.  Yardstick: numpy's float64 FFT under the
+# reference's conventions, same norm-relative 1e-6 criterion.
+
+@pytest.mark.parametrize("n,batch", [(3, 7), (5, 1), (6, 3), (12, 100), (100, 33), (1000, 9), (1536, 5), (4095, 3), (4097, 2),
+                                     (44100, 2), (48000, 3), (65537, 1), (100000, 2), (3 << 20, 1)])
+def test_cfft_any_length(n, batch):
+    rng = np.random.default_rng(n)
+    x = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    assert f.get_error() == 0 and i.get_error() == 0, (f.get_log(), i.get_log())
+    assert f.kernel_name() == "bluestein" and f.workspace_bytes() > 0
+    y = x.copy()
+    assert f.transform(y) == 0
+    assert_parity(y, (np.fft.fft(x.astype(np.complex128), axis=-1) / n).astype(np.complex64), what="fwd n=%d" % n)
+    z = x.copy()
+    assert i.transform(z) == 0
+    assert_parity(z, (np.fft.ifft(x.astype(np.complex128), axis=-1) * n).astype(np.complex64), what="inv n=%d" % n)
+    assert i.transform(y) == 0
+    assert_parity(y, x, what="round trip n=%d" % n)
+
+
+def test_cfft_any_length_chunks():
+    """more rows than the 256 MiB convolution workspace holds (m = 2^18 per row of n = 100000): the batch is walked in chunks"""
+    import torch
+    n, batch = 100000, 200
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
+    x = d.clone()
+    assert f.exec_device(d, batch) == 0
+    pick = [0, 127, 128, 199]
+    y = d[pick].cpu().numpy().view(np.complex64).reshape(len(pick), n)
+    xp = x[pick].cpu().numpy().view(np.complex64).reshape(len(pick), n)
+    assert_parity(y, (np.fft.fft(xp.astype(np.complex128), axis=-1) / n).astype(np.complex64), what="chunked fwd")
+    assert i.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    assert float((d - x).norm() / x.norm()) < 1e-6
+
+
+@pytest.mark.parametrize("size,batch", [(12, 50), (1000, 7), (48000, 3), (96000, 2), (3 << 17, 1)])
+def test_rfft_any_length(size, batch):
+    """packed real transforms of sizes that are multiples of 4: the reference's packing rules (amplitude
+    scaling, DC / Nyquist in bin 0, bin M/2 left un-conjugated) on a float64 FFT"""
+    m = size // 2
+    rng = np.random.default_rng(size)
+    x = rng.uniform(-1, 1, (batch, size)).astype(np.float32)
+    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+    assert f.get_error() == 0 and i.get_error() == 0, (f.get_log(), i.get_log())
+    c = np.zeros((batch, m), np.complex64)
+    assert f.transform(c, x) == 0
+    X = np.fft.fft(x.astype(np.float64), axis=-1)
+    want = np.empty((batch, m), np.complex128)
+    want[:, 0] = X[:, 0].real / size + 1j * X[:, m].real / size
+    want[:, 1:] = 2 * X[:, 1:m] / size
+    want[:, m // 2] = np.conj(want[:, m // 2])            # SURVEY.md section 8a fact 2
+    assert_parity(c, want.astype(np.complex64), what="r2c size=%d" % size)
+    r = np.zeros((batch, size), np.float32)
+    assert i.transform(c, r) == 0
+    assert_parity(r, x, what="rfft round trip size=%d" % size)
 
 
 def test_cfft_big_batch_chunks():
