@@ -216,6 +216,28 @@ def test_rfft_batched_in_place(size, batch):
     assert_parity(buf.view(np.float32), x, what="round trip")
 
 
+
+@pytest.mark.parametrize("size,batch", [(32768, 1), (32768, 259), (32768, 1030), (65536, 1), (65536, 257), (65536, 700)])
+def test_rfft_fused_big_sizes_ragged_batches(size, batch):
+    """real sizes 32768 (k_fft_lds<14>, 1024 lanes) and 65536 (k_rfft_lds15) — one persistent workgroup per CU:
+    fewer transforms than CUs, one more than a whole number of rounds, several rounds; device-resident, a few
+    transforms against the oracle, every transform through the round trip"""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(size + batch)
+    d = torch.rand((batch, size), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    x = d.clone()
+    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+    assert f.kernel_name() == ("k_rfft_lds15" if size == 65536 else "k_fft_lds")
+    assert f.exec_device(d, batch) == 0
+    pick = sorted({0, batch // 2, batch - 1})
+    spec = d[pick].cpu().numpy().view(np.complex64)
+    assert_parity(spec, oracle.rfft_forward(x[pick].cpu().numpy()), what="fwd size=%d batch=%d" % (size, batch))
+    assert i.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    err = (d - x).reshape(batch, -1).norm(dim=1) / x.reshape(batch, -1).norm(dim=1)
+    assert float(err.max()) < 1e-6, float(err.max())
+
+
 def test_rfft_bad_sizes():
     for s in (0, 2, 3, 6, 1 << 26):                      # odd, or not a power of two and not a multiple of 4
         assert fa.Clrfft(0, s, True).get_error() == -30
