@@ -491,6 +491,7 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     if ((e = upload(p->bigtabs, all.data(), sizeof(cpx) * all.size()))) return e;
     // workspace: as many whole transforms as fit 256 MiB (at least one); exec walks the batch in such chunks
     size_t per = sizeof(cpx) * (size_t)n, cap = (size_t)256 << 20;
+    if (const char *mb = getenv("CLFA_BIG_CHUNK_MB")) cap = (size_t)(atoi(mb) > 0 ? atoi(mb) : 256) << 20;   // tuning switch, read once
     if ((e = p->scratch.ensure(per * (cap / per > 0 ? cap / per : 1)))) return e;
   }
   if (p->logn == kLds14Log) {

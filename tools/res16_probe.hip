@@ -49,6 +49,19 @@ template <int PROBE> static void run(const char *name, cpx *data, cpx *slots, cp
     }
     p1 /= cus;
     p2 /= cus;
+    if (PROBE == kProbeStamps) {   // spread over the workgroups (one per CU; workgroup b usually sits on XCD b % 8)
+      double mn = 1e30, mx = 0, xs[8] = {0};
+      for (int i = 0; i < cus; i++) {
+        const double t = (double)h[2 * i] + (double)h[2 * i + 1];
+        mn = t < mn ? t : mn;
+        mx = t > mx ? t : mx;
+        xs[i & 7] += t / (cus / 8);
+      }
+      printf("  per-workgroup busy cycles: min %.3f  avg %.3f  max %.3f M  (max/avg %.3f);  by blockIdx %% 8:", mn * 1e-6, (p1 + p2) * 1e-6,
+             mx * 1e-6, mx / (p1 + p2));
+      for (int x = 0; x < 8; x++) printf(" %.3f", xs[x] * 1e-6);
+      printf("\n");
+    }
   }
   printf("%-34s %8.3f ms  %6.2f TB/s alg", name, ms, batch * 65536.0 * 16 / ms * 1e-9);
   if (PROBE & kProbeStamps) printf("   phase1 %.1f  phase2 %.1f  kcycles per transform (s_memtime, 100 MHz ticks x?)", p1 / (batch / cus) * 1e-3, p2 / (batch / cus) * 1e-3);
