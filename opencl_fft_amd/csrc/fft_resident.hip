@@ -121,7 +121,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const cpx *base) {
 //   128 phase 1 only (phase 2 skipped), 256 each workgroup starts its address sequence at another
 //   column block (blockIdx rotates the 128-byte column offset; results are then garbage)
 enum { kProbeNoLoad = 1, kProbeNoStore = 2, kProbeNoBarrier = 4, kProbeNoSlot = 8, kProbeStamps = 16,
-       kProbeNoWait = 32, kProbeNoMath = 64, kProbePhase1Only = 128, kProbeRotate = 256, kProbeGridSync = 512 };
+       kProbeNoWait = 32, kProbeNoMath = 64, kProbePhase1Only = 128, kProbeRotate = 256, kProbeGridSync = 512,
+       kProbeSlots = 1024 };
+//   1024 time slots: every workgroup starts phase k no earlier than its own start + S[k] (slot lengths in 10 ns
+//   ticks at dbg[2048], dbg[2049]): read and write phases aligned chip-wide without any communication
 //   512 a grid-wide barrier at every phase boundary (counter at dbg[1024]; the stamps exclude the wait):
 //   what perfectly aligned read and write phases would be worth
 template <int PROBE> __device__ __forceinline__ void res_barrier() {
@@ -605,6 +608,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
   long b = blockIdx.x;
   unsigned long long clk1 = 0, clk2 = 0;
   unsigned epoch = 0;   // probe only (the host zeroes the counter before the launch)
+  unsigned long long slot_next = 0, slot_p1 = 0, slot_p2 = 0;   // probe only
+  if constexpr (PROBE & kProbeSlots) {
+    slot_next = __builtin_amdgcn_s_memrealtime();
+    slot_p1 = dbg[2048];
+    slot_p2 = dbg[2049];
+  }
   // blocks 0 and 1 of the first transform
   if constexpr (!(PROBE & kProbeNoLoad)) {
     const ResLane L0 = lane();
@@ -637,6 +646,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     if constexpr (PROBE & kProbeGridSync) {
       res_probe_grid_sync(dbg, epoch);
       t0 = __builtin_amdgcn_s_memtime();
+    }
+    if constexpr (PROBE & kProbeSlots) {
+      slot_next += slot_p1;
+      while ((long long)(__builtin_amdgcn_s_memrealtime() - slot_next) < 0) __builtin_amdgcn_s_sleep(8);
+      if constexpr (PROBE & kProbeStamps) t0 = __builtin_amdgcn_s_memtime();
     }
     // ---- phase 2: row blocks in the order slot (its data are in the landing registers by now), AGPR
     // (the accumulation file is then free for the next transform's block 0), VGPR, LDS.  A block's results
@@ -688,6 +702,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     }
     if constexpr (PROBE & kProbeStamps) clk2 += __builtin_amdgcn_s_memtime() - t0;
     if constexpr (PROBE & kProbeGridSync) res_probe_grid_sync(dbg, epoch);
+    if constexpr (PROBE & kProbeSlots) {
+      slot_next += slot_p2;
+      while ((long long)(__builtin_amdgcn_s_memrealtime() - slot_next) < 0) __builtin_amdgcn_s_sleep(8);
+    }
   }
   if constexpr (PROBE & kProbeStamps) {
     if (tid == 0) {

@@ -68,6 +68,34 @@ template <int PROBE> static void run(const char *name, cpx *data, cpx *slots, cp
   printf("\n");
 }
 
+// time slots (PROBE 1024): phase k of every workgroup starts no earlier than (its start) + S[k]
+static void run_slots(cpx *data, cpx *slots, cpx *tabs, unsigned long long *dbg, long batch, int cus, unsigned p1, unsigned p2) {
+  unsigned long long h[2] = {p1, p2};
+  CK(hipMemcpy(dbg + 2048, h, 16, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto launch = [&] { hipLaunchKernelGGL((k_fft_res16<true, false, 1024 | 16>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, dbg); };
+  for (int i = 0; i < 10; i++) launch();
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 40; i++) launch();
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= 40;
+  std::vector<unsigned long long> st(2 * cus);
+  CK(hipMemcpy(st.data(), dbg, st.size() * 8, hipMemcpyDeviceToHost));
+  double a1 = 0, a2 = 0;
+  for (int i = 0; i < cus; i++) {
+    a1 += st[2 * i];
+    a2 += st[2 * i + 1];
+  }
+  printf("slots %5.2f + %5.2f us                 %8.3f ms  %6.2f TB/s alg   busy phase1 %.1f phase2 %.1f kcycles per transform\n", p1 * 0.01, p2 * 0.01,
+         ms, batch * 65536.0 * 16 / ms * 1e-9, a1 / cus / (batch / cus) * 1e-3, a2 / cus / (batch / cus) * 1e-3);
+}
+
 // the same work as `parts` launches of batch / parts transforms each: kernel boundaries keep the
 // workgroups' read and write phases aligned chip-wide
 static void run_split(cpx *data, cpx *slots, cpx *tabs, long batch, int cus, int parts) {
@@ -134,8 +162,8 @@ int main() {
   CK(hipMalloc(&data, batch * 65536 * 8));
   CK(hipMalloc(&slots, (size_t)cus * 32768));
   CK(hipMalloc(&tabs, 1792 * 8));
-  CK(hipMalloc(&dbg, 16384));
-  CK(hipMemset(dbg, 0, 16384));
+  CK(hipMalloc(&dbg, 32768));
+  CK(hipMemset(dbg, 0, 32768));
   CK(hipMemset(data, 0, batch * 65536 * 8));
   std::vector<cpx> t(1792);
   for (int i = 0; i < 1792; i++) t[i] = mk((float)cos(i * 0.001), (float)sin(i * 0.001));   // unit-modulus stand-ins: timing only
@@ -143,6 +171,10 @@ int main() {
   printf("k_fft_res16 probe: %ld transforms, %d workgroups\n", batch, cus);
   run<0>("full", data, slots, tabs, dbg, batch, cus);
   run<16>("full + stamps", data, slots, tabs, dbg, batch, cus);
+  for (unsigned p1 : {2300u, 2400u, 2500u, 2600u, 2700u})
+    for (unsigned p2 : {2300u, 2400u, 2500u, 2600u}) run_slots(data, slots, tabs, dbg, batch, cus, p1, p2);
+  run<0>("full (again)", data, slots, tabs, dbg, batch, cus);
+  if (getenv("PROBE_SLOTS_ONLY")) return 0;
   run<1 | 16>("no loads", data, slots, tabs, dbg, batch, cus);
   run<2 | 16>("no stores", data, slots, tabs, dbg, batch, cus);
   run<1 | 2 | 8 | 16>("no global traffic at all", data, slots, tabs, dbg, batch, cus);
