@@ -156,6 +156,53 @@ __global__ __launch_bounds__(256) void k_seg_grp(char *dst, const char *src, lon
   if (acc == 123.456f) *sink = acc;
 }
 
+
+// The resident FFT kernel's memory behaviour with its arithmetic as dummy work: one 256-lane workgroup per CU
+// (one wave per SIMD), a matrix (256 x 2048 B) at a time, in place.  Phase 1 reads the 16 column blocks, GRP adjacent
+// blocks per step with the step's loads issued before WORK dependent v_pk_fma per block (the loads of the next step
+// fly behind them: two steps in flight); phase 2 writes 16 column blocks the same way.  GRP = 1: the kernel as it
+// is; GRP = 4: four adjacent column blocks per burst (512 contiguous bytes requested together).
+template <int GRP> __global__ __launch_bounds__(256) void k_resident_model(char *data, long mats, int work, float *sink) {
+  const int l = threadIdx.x, c = l & 15, r0 = l >> 4;
+  f2 acc = {1.0f, 0.5f};
+  const f2 mm = {0.999f, 1.001f}, cc = {1e-3f, -1e-3f};
+  auto busy = [&](int n) {
+    for (int i = 0; i < n; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(mm), "v"(cc));
+  };
+  for (long m = blockIdx.x; m < mats; m += gridDim.x) {
+    char *d = data + m * 524288;
+    f2 cur[16 * GRP], nxt[16 * GRP];
+    auto load = [&](f2 (&r)[16 * GRP], int cb) {
+      const long off = (long)r0 * 2048 + cb * 128 + c * 8;
+#pragma unroll
+      for (int e = 0; e < 16; e++)
+#pragma unroll
+        for (int g = 0; g < GRP; g++) r[e * GRP + g] = ld8<true>((const f2 *)(d + off + g * 128 + (long)e * 32768));
+    };
+    load(cur, 0);
+#pragma unroll 1
+    for (int cb = 0; cb < 16; cb += GRP) {
+      load(nxt, (cb + GRP) & 15);   // (the last step re-reads block 0: one extra step of 16 / GRP + 1, same for every GRP ratio-wise)
+      busy(work * GRP);
+#pragma unroll
+      for (int i = 0; i < 16 * GRP; i++) {
+        acc += cur[i];
+        cur[i] = nxt[i];
+      }
+    }
+#pragma unroll 1
+    for (int cb = 0; cb < 16; cb += GRP) {
+      busy(work * GRP);
+      const long off = (long)r0 * 2048 + cb * 128 + c * 8;
+#pragma unroll
+      for (int e = 0; e < 16; e++)
+#pragma unroll
+        for (int g = 0; g < GRP; g++) st8<true>((f2 *)(d + off + g * 128 + (long)e * 32768), acc + f2{(float)e, (float)g});
+    }
+  }
+  if (acc.x == 123.456f) *sink = acc.y;
+}
+
 // ---------------------------------------------------------------- issue
 // OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_add_f32, 3 v_pk_mul_f32, 4 v_accvgpr_write+read pair, 5 v_add_f32
 template <int OP> __global__ void k_issue(float *out, int iters) {
@@ -316,6 +363,31 @@ int main(int argc, char **argv) {
         std::sort(v.begin(), v.end());
         printf("%-32s %s  %6.2f / %6.2f / %6.2f\n", sh.name, (idx >= 5 && idx < 10) ? "ip" : "  ", by / v.back() * 1e-9, by / v[v.size() / 2] * 1e-9, by / v.front() * 1e-9);
         idx++;
+      }
+    }
+
+    printf("\n[model] the resident kernel's memory behaviour with dummy arithmetic (WORK v_pk_fma per block and phase, one wave\n"
+           "        per SIMD): ms per pass over 4096 matrices, in place; TB/s = 2 x 2 GiB / time\n");
+    {
+      struct Shape { const char *name; std::function<void()> launch; std::vector<float> ms; };
+      std::vector<Shape> shapes;
+      for (int work : {0, 50, 100}) {
+        static char names[16][64];
+        static int ni = 0;
+        snprintf(names[ni], 64, "work %3d  1 block / step ", work);
+        shapes.push_back({names[ni++], [&, work] { hipLaunchKernelGGL((k_resident_model<1>), dim3(cus), dim3(256), 0, 0, a, mats, work, sink); }, {}});
+        snprintf(names[ni], 64, "work %3d  2 blocks / step", work);
+        shapes.push_back({names[ni++], [&, work] { hipLaunchKernelGGL((k_resident_model<2>), dim3(cus), dim3(256), 0, 0, a, mats, work, sink); }, {}});
+        snprintf(names[ni], 64, "work %3d  4 blocks / step", work);
+        shapes.push_back({names[ni++], [&, work] { hipLaunchKernelGGL((k_resident_model<4>), dim3(cus), dim3(256), 0, 0, a, mats, work, sink); }, {}});
+      }
+      for (int round = 0; round < 4; round++)
+        for (auto &sh : shapes) sh.ms.push_back(time_launches(6, 30, sh.launch));
+      const double by = 2.0 * (double)mats * 524288;
+      for (auto &sh : shapes) {
+        std::vector<float> v = sh.ms;
+        std::sort(v.begin(), v.end());
+        printf("%-28s %7.3f ms (min %.3f)  %6.2f TB/s\n", sh.name, v[v.size() / 2], v.front(), by / v[v.size() / 2] * 1e-9);
       }
     }
     CK(hipFree(a));
