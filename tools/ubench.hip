@@ -203,6 +203,51 @@ template <int GRP> __global__ __launch_bounds__(256) void k_resident_model(char 
   if (acc.x == 123.456f) *sink = acc.y;
 }
 
+
+// the same traffic with the phases interleaved inside the CU: step k writes column block k of matrix m and reads
+// column block k of matrix m + grid (what a pipeline that drains transform b row block by row block while it fills
+// transform b + 1 column block by column block would do; the register file could just hold it: c <= r cells)
+__global__ __launch_bounds__(256) void k_resident_model_il(char *data, long mats, int work, float *sink) {
+  const int l = threadIdx.x, c = l & 15, r0 = l >> 4;
+  f2 acc = {1.0f, 0.5f};
+  const f2 mm = {0.999f, 1.001f}, cc = {1e-3f, -1e-3f};
+  auto busy = [&](int n) {
+    for (int i = 0; i < n; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(mm), "v"(cc));
+  };
+  f2 cur[16], nxt[16];
+  auto load = [&](f2 (&r)[16], long m, int cb) {
+    const char *d = data + m * 524288 + (long)r0 * 2048 + cb * 128 + c * 8;
+#pragma unroll
+    for (int e = 0; e < 16; e++) r[e] = ld8<true>((const f2 *)(d + (long)e * 32768));
+  };
+  long m = blockIdx.x;
+  if (m >= mats) return;
+  // prologue: read the first matrix (phase 1 alone)
+  load(cur, m, 0);
+  for (int cb = 0; cb < 16; cb++) {
+    load(nxt, m, (cb + 1) & 15);
+    busy(work);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc += cur[i]; cur[i] = nxt[i]; }
+  }
+  for (; m < mats; m += gridDim.x) {
+    const long mn = m + gridDim.x < mats ? m + gridDim.x : m;   // the last round re-reads its own matrix
+    load(cur, mn, 0);
+#pragma unroll 1
+    for (int cb = 0; cb < 16; cb++) {
+      load(nxt, mn, (cb + 1) & 15);
+      busy(work);          // row block cb of matrix m
+      char *d = data + m * 524288 + (long)r0 * 2048 + cb * 128 + c * 8;
+#pragma unroll
+      for (int e = 0; e < 16; e++) st8<true>((f2 *)(d + (long)e * 32768), acc + f2{(float)e, 1.f});
+      busy(work);          // column block cb of matrix m + grid
+#pragma unroll
+      for (int i = 0; i < 16; i++) { acc += cur[i]; cur[i] = nxt[i]; }
+    }
+  }
+  if (acc.x == 123.456f) *sink = acc.y;
+}
+
 // ---------------------------------------------------------------- issue
 // OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_add_f32, 3 v_pk_mul_f32, 4 v_accvgpr_write+read pair, 5 v_add_f32
 template <int OP> __global__ void k_issue(float *out, int iters) {
@@ -372,7 +417,7 @@ int main(int argc, char **argv) {
       struct Shape { const char *name; std::function<void()> launch; std::vector<float> ms; };
       std::vector<Shape> shapes;
       for (int work : {0, 50, 100}) {
-        static char names[16][64];
+        static char names[24][64];
         static int ni = 0;
         snprintf(names[ni], 64, "work %3d  1 block / step ", work);
         shapes.push_back({names[ni++], [&, work] { hipLaunchKernelGGL((k_resident_model<1>), dim3(cus), dim3(256), 0, 0, a, mats, work, sink); }, {}});
@@ -380,6 +425,8 @@ int main(int argc, char **argv) {
         shapes.push_back({names[ni++], [&, work] { hipLaunchKernelGGL((k_resident_model<2>), dim3(cus), dim3(256), 0, 0, a, mats, work, sink); }, {}});
         snprintf(names[ni], 64, "work %3d  4 blocks / step", work);
         shapes.push_back({names[ni++], [&, work] { hipLaunchKernelGGL((k_resident_model<4>), dim3(cus), dim3(256), 0, 0, a, mats, work, sink); }, {}});
+        snprintf(names[ni], 64, "work %3d  phases interleaved", work);
+        shapes.push_back({names[ni++], [&, work] { hipLaunchKernelGGL(k_resident_model_il, dim3(cus), dim3(256), 0, 0, a, mats, work, sink); }, {}});
       }
       for (int round = 0; round < 4; round++)
         for (auto &sh : shapes) sh.ms.push_back(time_launches(6, 30, sh.launch));
