@@ -54,3 +54,22 @@ class ShardedBatch:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
+
+    def all_gather(self, local):
+        """every rank's shard, concatenated along the batch axis, on every rank (optional, for a
+        caller that wants the whole result everywhere — an exchange over xGMI after the transforms, never part of
+        their time).  `local` holds this rank's `count` rows; ragged shards travel padded to the largest."""
+        import torch
+        if not (self.active and self.world > 1):
+            return local
+        import torch.distributed as dist
+        if local.shape[0] != self.count:
+            raise ValueError("local shard has %d rows, this rank owns %d" % (local.shape[0], self.count))
+        most = shard_range(self.total, 0, self.world)[1]
+        send = local
+        if self.count < most:
+            pad = torch.zeros((most - self.count,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            send = torch.cat([local, pad], dim=0)
+        parts = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(parts, send.contiguous())
+        return torch.cat([parts[r][:shard_range(self.total, r, self.world)[1]] for r in range(self.world)], dim=0)

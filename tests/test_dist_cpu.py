@@ -49,6 +49,10 @@ def _worker(rank, world, port, total, n, out_dir):
     tmax = sb.reduce_max(1.0 + rank)
     np.save(os.path.join(out_dir, "y%d.npy" % rank), y)
     np.save(os.path.join(out_dir, "meta%d.npy" % rank), np.array([tot, tmax, sb.start, sb.count]))
+    # the optional exchange of SURVEY.md section 8e: every rank ends up with the whole (ragged) batch
+    import torch
+    full = sb.all_gather(torch.from_numpy(np.ascontiguousarray(y).view(np.float32).reshape(sb.count, 2 * n)))
+    np.save(os.path.join(out_dir, "full%d.npy" % rank), full.numpy())
     dist.destroy_process_group()
 
 
@@ -71,6 +75,9 @@ def test_two_rank_gloo_sharded_fft(tmp_path, total):
         assert abs(m[0] - e) <= 1e-9 * e          # checksum of checksums agrees on every rank
         assert m[1] == 2.0                        # max over ranks of (1 + rank)
     assert [int(m[3]) for m in metas] == [c for _, c in (shard_range(total, r, world) for r in range(world))]
+    for r in range(world):                        # all_gather: the whole result on every rank, bit for bit
+        full = np.load(tmp_path / ("full%d.npy" % r))
+        assert np.array_equal(full.view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
 
 
 # ---- eight ranks, the product's own Python path, the library mocked at the launch boundary -----------
