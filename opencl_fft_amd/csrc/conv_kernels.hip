@@ -11,6 +11,8 @@
 //                deterministic order, 16-byte coalesced streaming of both rings
 //   k_pconv_inv  c2r + inverse FFT + overlap-add + 1/bins scaling fused
 // The rings are channels x nparts x bins complex64, resident in HBM.
+#include <cstdlib>
+
 #include "fft_wg.hpp"
 
 namespace clfa {
@@ -179,21 +181,35 @@ __global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, co
   }
 }
 
-// acc[0] += acc[1] + ... + acc[nsplit-1], ascending (deterministic)
-__global__ __launch_bounds__(256) void k_pconv_reduce(cpx *__restrict__ acc, long total2, int nsplit) {
+// partial accumulators k = base, base + stride, ..., (count of them, base = blockIdx.y * count * stride, as far as
+// nsplit goes) summed in ascending order into accumulator `base`: deterministic.  One launch with count = nsplit sums
+// everything; many segments (a single channel with a long filter) are summed as a two-level tree so that the sum is
+// not one workgroup's serial walk over hundreds of strided loads.
+__global__ __launch_bounds__(256) void k_pconv_reduce(cpx *__restrict__ acc, long total2, int nsplit, int count, int stride) {
+  const int base = blockIdx.y * count * stride;
   for (long g = blockIdx.x * 256L + threadIdx.x; g < total2; g += (long)gridDim.x * 256) {
-    cpx s = acc[g];
-    for (int k = 1; k < nsplit; k++) s = cadd(s, acc[(long)k * total2 + g]);
-    acc[g] = s;
+    cpx s = acc[(long)base * total2 + g];
+    for (int k = 1; k < count && base + k * stride < nsplit; k++) s = cadd(s, acc[(long)(base + k * stride) * total2 + g]);
+    acc[(long)base * total2 + g] = s;
   }
 }
 
 int pconv_mac_split(const PconvGeom &g) {
-  // split only when channels x bins/2 gives fewer than ~64K lanes (config 4 has 131072: no split)
+  // split only when channels x bins/2 gives fewer than ~64K lanes (config 4 has 131072: no split).  A single
+  // channel with a long filter — the reference harness' own case, csound/tests.py — has to put the whole chip on
+  // the partition axis to stream its rings at HBM speed: up to 512 segments of at least 4 partitions
+  // (CLFA_PCONV_SPLIT_MAX: tuning switch, read once).
+  static const int cap = [] {
+    const char *e = getenv("CLFA_PCONV_SPLIT_MAX");
+    const int v = e ? atoi(e) : 512;
+    return v < 1 ? 1 : v;
+  }();
   long lanes = (long)g.channels * (g.bins / 2);
-  long want = (64L * 1024 + lanes - 1) / lanes;
-  if (want > 64) want = 64;
-  if (want > g.nparts / 4) want = g.nparts / 4;
+  const long target = lanes <= 1024 ? 128L * 1024 : 64L * 1024;   // measured: the finer split pays up to pts = 2048
+  long want = (target + lanes - 1) / lanes;
+  if (lanes >= 64L * 1024) want = 1;
+  if (want > cap) want = cap;
+  if (want > g.nparts / 4) want = g.nparts / 4;   // (segments of 1 or 2 partitions: measured, mixed — not kept)
   return want < 1 ? 1 : (int)want;
 }
 
@@ -210,7 +226,13 @@ hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *rin
   if (e != hipSuccess || nsplit == 1 || !reduce) return e;
   long total2 = total * 2, rgrid = (total2 + 255) / 256;
   if (rgrid > 4096) rgrid = 4096;
-  hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid), dim3(256), 0, s, acc, total2, nsplit);
+  if (nsplit > 64) {   // groups of 32, then the group sums
+    const int groups = (nsplit + 31) / 32;
+    hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid, groups), dim3(256), 0, s, acc, total2, nsplit, 32, 1);
+    hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid, 1), dim3(256), 0, s, acc, total2, nsplit, groups, 32);
+  } else {
+    hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid, 1), dim3(256), 0, s, acc, total2, nsplit, nsplit, 1);
+  }
   return hipGetLastError();
 }
 
