@@ -184,13 +184,29 @@ __global__ __launch_bounds__(256) void k_pconv_mac(const cpx *__restrict__ A, co
 // partial accumulators k = base, base + stride, ..., (count of them, base = blockIdx.y * count * stride, as far as
 // nsplit goes) summed in ascending order into accumulator `base`: deterministic.  One launch with count = nsplit sums
 // everything; many segments (a single channel with a long filter) are summed as a two-level tree so that the sum is
-// not one workgroup's serial walk over hundreds of strided loads.
+// not one workgroup's serial walk over hundreds of strided loads.  MAXC > 0: count <= MAXC, all loads are issued
+// before the first add (one memory latency instead of `count`).
+template <int MAXC>
 __global__ __launch_bounds__(256) void k_pconv_reduce(cpx *__restrict__ acc, long total2, int nsplit, int count, int stride) {
   const int base = blockIdx.y * count * stride;
   for (long g = blockIdx.x * 256L + threadIdx.x; g < total2; g += (long)gridDim.x * 256) {
-    cpx s = acc[(long)base * total2 + g];
-    for (int k = 1; k < count && base + k * stride < nsplit; k++) s = cadd(s, acc[(long)(base + k * stride) * total2 + g]);
-    acc[(long)base * total2 + g] = s;
+    if constexpr (MAXC > 0) {
+      cpx v[MAXC];
+#pragma unroll
+      for (int k = 0; k < MAXC; k++) {
+        const bool ok = k < count && base + k * stride < nsplit;
+        v[k] = acc[(long)(ok ? base + k * stride : base) * total2 + g];   // clamped: straight-line loads
+        if (!ok) v[k] = mk(0.f, 0.f);
+      }
+      cpx s = v[0];
+#pragma unroll
+      for (int k = 1; k < MAXC; k++) s = cadd(s, v[k]);
+      acc[(long)base * total2 + g] = s;
+    } else {
+      cpx s = acc[(long)base * total2 + g];
+      for (int k = 1; k < count && base + k * stride < nsplit; k++) s = cadd(s, acc[(long)(base + k * stride) * total2 + g]);
+      acc[(long)base * total2 + g] = s;
+    }
   }
 }
 
@@ -226,12 +242,21 @@ hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *rin
   if (e != hipSuccess || nsplit == 1 || !reduce) return e;
   long total2 = total * 2, rgrid = (total2 + 255) / 256;
   if (rgrid > 4096) rgrid = 4096;
+  auto sum = [&](int groups, int count, int stride) {   // the smallest unrolled form that holds `count`
+    const dim3 grid((int)rgrid, groups), block(256);
+    if (count <= 2) hipLaunchKernelGGL(k_pconv_reduce<2>, grid, block, 0, s, acc, total2, nsplit, count, stride);
+    else if (count <= 4) hipLaunchKernelGGL(k_pconv_reduce<4>, grid, block, 0, s, acc, total2, nsplit, count, stride);
+    else if (count <= 8) hipLaunchKernelGGL(k_pconv_reduce<8>, grid, block, 0, s, acc, total2, nsplit, count, stride);
+    else if (count <= 16) hipLaunchKernelGGL(k_pconv_reduce<16>, grid, block, 0, s, acc, total2, nsplit, count, stride);
+    else if (count <= 32) hipLaunchKernelGGL(k_pconv_reduce<32>, grid, block, 0, s, acc, total2, nsplit, count, stride);
+    else hipLaunchKernelGGL(k_pconv_reduce<64>, grid, block, 0, s, acc, total2, nsplit, count, stride);
+  };
   if (nsplit > 64) {   // groups of 32, then the group sums
     const int groups = (nsplit + 31) / 32;
-    hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid, groups), dim3(256), 0, s, acc, total2, nsplit, 32, 1);
-    hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid, 1), dim3(256), 0, s, acc, total2, nsplit, groups, 32);
+    sum(groups, 32, 1);
+    sum(1, groups, 32);
   } else {
-    hipLaunchKernelGGL(k_pconv_reduce, dim3((int)rgrid, 1), dim3(256), 0, s, acc, total2, nsplit, nsplit, 1);
+    sum(1, nsplit, 1);
   }
   return hipGetLastError();
 }
