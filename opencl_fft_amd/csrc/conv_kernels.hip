@@ -523,7 +523,9 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
 }
 
 bool pconv_fused_ok(const PconvGeom &g, const DeviceInfo &di) {
-  return g.logb >= 9 && g.logb <= 12 && g.channels * 2 >= di.num_cus;
+  // one workgroup per channel: below ~5/8 of the CUs the chip is too empty for it (measured at pts 1024, 94
+  // partitions: 128 channels 53 us fused against 46 us on the three-kernel chain, 160 channels 56 against 59)
+  return g.logb >= 9 && g.logb <= 12 && g.channels * 8 >= di.num_cus * 5;
 }
 
 template <int LOGB>

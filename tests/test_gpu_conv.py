@@ -242,8 +242,8 @@ def test_config4_full_size_properties():
         assert_parity(y_h[:, c], want, tol=CTOL, what="channel %d" % c)
 
 
-@pytest.mark.parametrize("pts,nparts,channels,blocks,tv", [(512, 5, 130, 7, False), (1024, 4, 128, 6, True),
-                                                          (2048, 3, 140, 5, False), (4096, 2, 128, 4, True)])
+@pytest.mark.parametrize("pts,nparts,channels,blocks,tv", [(512, 5, 162, 7, False), (1024, 4, 160, 6, True),
+                                                          (2048, 3, 170, 5, False), (4096, 2, 160, 4, True)])
 def test_pconv_fused_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
     """enough channels to select the one-launch-per-block kernel (forward + MAC + inverse per channel)"""
     s = util.lcg_half(21 + pts, channels * (pts * nparts + 2 * pts * blocks))
