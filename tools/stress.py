@@ -20,6 +20,22 @@ for n, batch, iters in [(65536, 4096, 300), (65536, 777, 300), (32768, 8192, 200
     print("n=%d batch=%d: %d round trips, worst relL2 after 10 round trips %.2e" % (n, batch, iters, worst), flush=True)
 print("OK")
 
+# the one-workgroup-per-CU real kernels (k_fft_lds<14>, k_rfft_lds15): r2c then c2r is the identity
+for size, batch, iters in [(32768, 8192, 200), (32768, 259, 300), (65536, 4096, 200), (65536, 257, 300)]:
+    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+    x = torch.rand((batch, size), device="cuda") * 2 - 1
+    d = x.clone()
+    worst = 0.0
+    for k in range(iters):
+        assert f.exec_device(d, batch) == 0 and i.exec_device(d, batch) == 0
+        if k % 10 == 9:
+            err = float((d - x).norm() / x.norm())
+            worst = max(worst, err)
+            assert err < 2e-5, (size, batch, k, err)
+            d.copy_(x)
+    print("real size=%d batch=%d: %d round trips, worst relL2 after 10 round trips %.2e" % (size, batch, iters, worst), flush=True)
+print("real sizes OK")
+
 # small sizes through the staged kernel, ragged batch counts, complex and packed real
 import numpy as np
 rng = np.random.default_rng(3)
