@@ -253,6 +253,7 @@ struct clfa_fft {
   // there; complex plans when CLFA_LDS14 says so — resolved at creation)
   bool lds14 = false;
   bool rlds15 = false;   // packed real size 65536: k_rfft_lds15 (two 16384-point runs per transform, one HBM pass)
+  long spread_below = 0; // real sizes 32768 / 65536: batches up to this run the four-step pair + pack kernel instead
   // any other length (extension): Bluestein around two power-of-two plans of length blue_m
   int blue_m = 0;
   clfa_fft *blue_f = nullptr, *blue_i = nullptr;
@@ -499,8 +500,15 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     p->lds14 = real || (sw ? atoi(sw) != 0 : kLds14Complex);
   }
   p->rlds15 = real && p->logn == 15 && !getenv("CLFA_NO_RLDS15");   // tuning switch, read once
-  if (p->rlds15) rowlog = kLds14Log;   // its tables are the 16384-point lane tables
-  if (rowlog <= kLdsMaxLog || p->lds14 || p->rlds15) {
+  // The fused real kernels put one workgroup on a transform (13-23 us for a single one); a few transforms are
+  // faster spread over the column / row blocks of the four-step pair plus the pack kernel (11 us): real plans of
+  // these two sizes carry both sets of tables and exec picks by batch (p->spread_below).
+  const bool lane14 = p->lds14 || p->rlds15;
+  const bool both = lane14 && real;
+  const int fourlog = rowlog;
+  if (lane14) rowlog = kLds14Log;   // the lane tables are the 16384-point ones
+  if (both) p->spread_below = p->di.num_cus / 8;   // measured crossover: between 32 and 64 transforms
+  if (rowlog <= kLdsMaxLog || lane14) {
     if (kLdsTwoLevel(rowlog)) {
       // n = 8192 / 16384: lane-addressed tables (internal.hpp, kLane13Size / kLane14Size), every value rounded from double
       h.clear();
@@ -520,7 +528,10 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     }
     if ((e = upload(p->half, h.data(), sizeof(cpx) * h.size()))) return e;
     p->tabs.half = (const cpx *)p->half.p;
-  } else {
+  }
+  if (!(rowlog <= kLdsMaxLog || lane14) || both) {
+    rowlog = fourlog;
+    rown = 1 << rowlog;
     std::vector<cpx> all;
     fill_fourstep_tables(all, rowlog);
     if ((e = upload(p->four, all.data(), sizeof(cpx) * all.size()))) return e;
@@ -636,11 +647,12 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
     if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, n, batch, s));
     return CLFA_SUCCESS;
   }
-  if (p->rlds15) {
+  const bool spread = p->real && batch <= p->spread_below;   // a few transforms: one workgroup each would be slower
+  if (p->rlds15 && !spread) {
     HIP_TRY(launch_rfft_lds15(p->fwd, d, p->tabs, batch, p->di, s));
     return CLFA_SUCCESS;
   }
-  if (p->logn <= kLdsMaxLog || p->lds14) {
+  if (p->logn <= kLdsMaxLog || (p->lds14 && !spread)) {
     int mode = !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R);
     HIP_TRY(launch_fft_lds(p->logn, p->fwd, mode, scale, d, p->tabs, batch, p->di, s));
     return CLFA_SUCCESS;

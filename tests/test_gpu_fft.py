@@ -217,11 +217,13 @@ def test_rfft_batched_in_place(size, batch):
 
 
 
-@pytest.mark.parametrize("size,batch", [(32768, 1), (32768, 259), (32768, 1030), (65536, 1), (65536, 257), (65536, 700)])
+@pytest.mark.parametrize("size,batch", [(32768, 1), (32768, 32), (32768, 33), (32768, 259), (32768, 1030),
+                                        (65536, 1), (65536, 32), (65536, 33), (65536, 257), (65536, 700)])
 def test_rfft_fused_big_sizes_ragged_batches(size, batch):
     """real sizes 32768 (k_fft_lds<14>, 1024 lanes) and 65536 (k_rfft_lds15) — one persistent workgroup per CU:
-    fewer transforms than CUs, one more than a whole number of rounds, several rounds; device-resident, a few
-    transforms against the oracle, every transform through the round trip"""
+    fewer transforms than CUs, one more than a whole number of rounds, several rounds; up to 32 transforms run
+    spread over the four-step pair + pack kernel instead (both sides of that switch are here); device-resident,
+    a few transforms against the oracle, every transform through the round trip"""
     import torch
     g = torch.Generator(device="cuda").manual_seed(size + batch)
     d = torch.rand((batch, size), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
