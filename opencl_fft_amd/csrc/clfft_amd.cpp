@@ -915,7 +915,7 @@ int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void
     if (in2) p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;
     HIP_TRY(launch_pconv_fused(p->g, (const float *)in1, (const float *)in2, (cpx *)p->ringA.p, (cpx *)p->ringB.p,
                                (float *)p->tail.p, (float *)out, frame1, frame2, p->wp, (const cpx *)p->half.p,
-                               (const cpx *)p->w2f.p, (const cpx *)p->w2i.p, s));
+                               (const cpx *)p->w2f.p, (const cpx *)p->w2i.p, s, p->g.channels < p->di.num_cus));
     return CLFA_SUCCESS;
   }
   const bool lds = p->g.logb <= kLdsMaxLog;

@@ -361,7 +361,7 @@ hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail,
 // __syncthreads(): the new spectrum frame is stored to the ring and re-read by the same
 // workgroup (workgroup-scope visibility), the accumulator lives in LDS.
 // ---------------------------------------------------------------------------------
-template <int LOGB, bool TV>
+template <int LOGB, bool TV, bool DEEP = false>
 __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ in1, const float *__restrict__ in2,
                                                      cpx *__restrict__ ringA, cpx *__restrict__ ringB,
                                                      float *__restrict__ tail, float *__restrict__ out, int frame1,
@@ -443,8 +443,7 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
 #pragma unroll
     for (int k = 0; k < IPT; k++) s0[k] = s1[k] = mk(0.f, 0.f);
     int fr = wp;
-#pragma unroll 4
-    for (int p = 0; p < nparts; p++) {
+    auto step = [&](int p) {
       cpx2 av[IPT], bv[IPT];
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
@@ -462,6 +461,15 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
         s1[k] = cadd(s1[k], cmul_plain(av[k].b, bv[k].b));
       }
       fr = fr + 1 < nparts ? fr + 1 : 0;
+    };
+    // loads of 4 partitions in flight per lane fill the memory system when every CU has a workgroup; with fewer
+    // channels than CUs (DEEP) a workgroup is alone with its latency and 8 pay (160 channels: 55.5 -> 51.8 us)
+    if constexpr (DEEP) {
+#pragma unroll 8
+      for (int p = 0; p < nparts; p++) step(p);
+    } else {
+#pragma unroll 4
+      for (int p = 0; p < nparts; p++) step(p);
     }
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
@@ -531,24 +539,26 @@ bool pconv_fused_ok(const PconvGeom &g, const DeviceInfo &di) {
 template <int LOGB>
 static hipError_t launch_fused_one(const PconvGeom &g, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                                    float *tail, float *out, int frame1, int frame2, int wp, const cpx *half,
-                                   const cpx *w2f, const cpx *w2i, hipStream_t s) {
-  if (in2)
-    hipLaunchKernelGGL((k_pconv_fused<LOGB, true>), dim3(g.channels), dim3(256), 0, s, in1, in2, ringA, ringB, tail, out,
-                       frame1, frame2, wp, g.nparts, half, w2f, w2i);
-  else
-    hipLaunchKernelGGL((k_pconv_fused<LOGB, false>), dim3(g.channels), dim3(256), 0, s, in1, in2, ringA, ringB, tail, out,
-                       frame1, frame2, wp, g.nparts, half, w2f, w2i);
+                                   const cpx *w2f, const cpx *w2i, hipStream_t s, bool deep) {
+#define CLFA_FUSED(TVF, DP)                                                                                          \
+  hipLaunchKernelGGL((k_pconv_fused<LOGB, TVF, DP>), dim3(g.channels), dim3(256), 0, s, in1, in2, ringA, ringB, tail, out, \
+                     frame1, frame2, wp, g.nparts, half, w2f, w2i)
+  if (in2 && deep) CLFA_FUSED(true, true);
+  else if (in2) CLFA_FUSED(true, false);
+  else if (deep) CLFA_FUSED(false, true);
+  else CLFA_FUSED(false, false);
+#undef CLFA_FUSED
   return hipGetLastError();
 }
 
 hipError_t launch_pconv_fused(const PconvGeom &g, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                               float *tail, float *out, int frame1, int frame2, int wp, const cpx *half,
-                              const cpx *w2f, const cpx *w2i, hipStream_t s) {
+                              const cpx *w2f, const cpx *w2i, hipStream_t s, bool deep) {
   switch (g.logb) {
-    case 9: return launch_fused_one<9>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s);
-    case 10: return launch_fused_one<10>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s);
-    case 11: return launch_fused_one<11>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s);
-    case 12: return launch_fused_one<12>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s);
+    case 9: return launch_fused_one<9>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s, deep);
+    case 10: return launch_fused_one<10>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s, deep);
+    case 11: return launch_fused_one<11>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s, deep);
+    case 12: return launch_fused_one<12>(g, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, s, deep);
     default: return hipErrorInvalidValue;
   }
 }

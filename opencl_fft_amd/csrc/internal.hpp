@@ -113,7 +113,7 @@ hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail,
 bool pconv_fused_ok(const PconvGeom &g, const DeviceInfo &di);
 hipError_t launch_pconv_fused(const PconvGeom &g, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                               float *tail, float *out, int frame1, int frame2, int wp, const cpx *half,
-                              const cpx *w2f, const cpx *w2i, hipStream_t s);
+                              const cpx *w2f, const cpx *w2i, hipStream_t s, bool deep = false);   // deep: fewer channels than CUs
 constexpr int kPconvMaxLogBins = 15;   // pts up to 32768 (the reference harness' largest, csound/tests.py:13)
 // ends of the composed chain used when bins exceed the LDS FFT sizes
 hipError_t launch_pconv_pad(const float *in, long in_stride, cpx *work, int bins, int channels, hipStream_t s);
