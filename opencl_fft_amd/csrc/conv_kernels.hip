@@ -531,9 +531,9 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
 }
 
 bool pconv_fused_ok(const PconvGeom &g, const DeviceInfo &di) {
-  // one workgroup per channel: below ~5/8 of the CUs the chip is too empty for it (measured at pts 1024, 94
-  // partitions: 128 channels 53 us fused against 46 us on the three-kernel chain, 160 channels 56 against 59)
-  return g.logb >= 9 && g.logb <= 12 && g.channels * 8 >= di.num_cus * 5;
+  // one workgroup per channel: below ~8/15 of the CUs the chip is too empty for it (measured at pts 1024, 94
+  // partitions: 128 channels 48 us fused against 46 us on the three-kernel chain, 144 channels 50 against 56)
+  return g.logb >= 9 && g.logb <= 12 && g.channels * 15 >= di.num_cus * 8;
 }
 
 template <int LOGB>
