@@ -11,13 +11,18 @@ import csv, glob, json, os, shutil, sys
 def main(src, tag, key, kernel_substr, root):
     dst = os.path.join(root, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
-    for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    newest = lambda files: sorted(files, key=os.path.getmtime)[-1:]   # gpurun_out accumulates earlier runs
+    for f in newest(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)):
         shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
     for f in ("bench_unprofiled.json", "bench_driver_cmdline.json", "series_steps20.txt", "series_steps100.txt", "series_cold_start.txt", "summary.json"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "summary.json" else "pmc_summary.json"))
     acc = {}
-    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    counter_files = []
+    for d in glob.glob(os.path.join(src, "pmc_*")):
+        if os.path.isdir(d):
+            counter_files += newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
+    for f in counter_files:
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
