@@ -44,3 +44,25 @@ def test_programs_on_gpu(built, prog):
     r = subprocess.run([os.path.join(built, prog)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("OK"), r.stdout
+
+
+@pytest.mark.parametrize("prog", ["test_cfft", "test_rfft"])
+def test_reference_callers_compile_and_link_unchanged(built, prog, tmp_path):
+    """the reference's own caller programs, read where they lie (nothing is copied into the repo), compile against
+    include/ and link against libcl_fft.so without a change — the drop-in claim of SURVEY.md section 8b.  Only where
+    the reference tree exists (the authoring container); running them needs a GPU and is what tests/cpp/ covers."""
+    src = os.path.join("/root/reference", prog + ".cpp")
+    if not os.path.exists(src):
+        pytest.skip("no reference tree here")
+    exe = str(tmp_path / prog)
+    lib = os.path.join(ROOT, "opencl_fft_amd")
+    # fed through stdin so that its `#include "cl_fft.h"` resolves to include/ and not to the header lying next to it
+    with open(src, "rb") as f:
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-x", "c++", "-", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                               "-L", lib, "-lcl_fft", "-lclfft_amd", "-Wl,-rpath," + lib], stdin=f, cwd=str(tmp_path))
+    out = subprocess.check_output(["nm", "-C", "--undefined-only", exe]).decode()
+    assert "cl_fft::Cl" in out          # the class surface is resolved from the drop-in library
+    import opencl_fft_amd as fa
+    if fa.device_count() == 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode != 0         # no device: the program reports it and exits (no CPU fallback exists)
