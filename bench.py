@@ -3,8 +3,9 @@
 float32, 4096 batches per GPU, device-resident, in place.
 
     python bench.py --gpus 1 --steps 200 --warmup 20      (the defaults)
+    python bench.py --gpus N ...                           (starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      (the driver's launch line)
 
 A step = one pass of the hot path (one batched transform) over the rank's 4096 x 65536
 complex samples already resident in HBM.  Steps alternate forward / inverse plans on the
@@ -14,16 +15,24 @@ The path shards by batches: every rank owns its own 4096 transforms, no data-pat
 collective ("weak" scaling, config 5 of BASELINE.json); RCCL only carries the end-of-run
 checksum and the max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      algorithmic bytes (16 B per complex sample) / average launch
                 duration of the dominant kernel, measured here with HIP events on the launch stream
   cpu_baseline  the CPU restatement of the reference algorithm (oracle/, "port") timed on the
                 host cores over a bounded sample — a reported baseline, not the target
-Other workloads (--workload rfft | pconv) time configs 3 and 4 with the same machinery.
+  config.other_workloads   (N = 1 only) configs[2] and configs[3] of BASELINE.json — r2c + c2r of size
+                16384 x 8192 and the 256-channel partitioned convolution — timed in the same run with the
+                same machinery, each with ms_per_step and its own roofline block
+  ms_per_step_cold / roofline.frac_cold   the same K steps after the same W warm-up steps taken FIRST, before
+                the full-size self-check (the chip is still inside its ~20 ms start-up clock ramp then);
+                config.effective_warmup_launches counts what ran before the headline's timed region
+`--workload rfft | pconv` make one of the other configurations the headline of the line instead.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,20 +53,38 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bandwidth", action="store_true", help="skip the device copy/read/write yardsticks")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the full-size property check before the warm-up")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold timed region taken before the self-check")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="headline workload only (profiling runs); default: N = 1 runs also time the other two configs")
     ap.add_argument("--series-out", default="", help="write the per-launch times (ms) of the timed region to this file")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`bench.py --gpus N` without an outer launcher: start the N ranks ourselves (torch.distributed.run as a
+    CHILD process, before this process has imported torch or touched a GPU), relay their output and exit
+    with their code.  Never an exec: a process that has initialised the GPU must not be replaced."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def traffic_from_profiles(key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json,
     written by tools/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE with the gfx950 corrections
-    of MI355X_MICROARCH.md); None when no measurement is committed."""
+    of MI355X_MICROARCH.md); (None, None) when no measurement is committed."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+            e = json.load(f).get(key, {})
+            return e.get("hbm_bytes_per_launch"), e.get("source")
     except (OSError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline_c2c(n, sample):
@@ -75,8 +102,159 @@ def cpu_baseline_c2c(n, sample):
             "sample": "%d transforms of N=%d (%.1f s wall, OpenMP over batches)" % (sample, n, dt)}
 
 
+class Workload:
+    """one configuration of BASELINE.json, device-resident: step(k) launches one pass on `stream`"""
+
+    def __init__(self, name, fa, torch, dev, local, rank, world, batch_override, stream):
+        self.name, self.torch, self.stream = name, torch, stream
+        self.extra = {}
+        self.plans = None
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        self.gen = g
+        if name == "c2c":
+            from opencl_fft_amd.dist import ShardedBatch
+            n = 65536
+            # weak scaling: 4096 transforms per GPU (config 5 = 32768 over 8 GPUs); the global batch is
+            # split into contiguous blocks, rank r owns [start, start+count)
+            shard = ShardedBatch((batch_override or 4096) * world, rank, world)
+            self.batch = batch = shard.count
+            self.extra["global_batch"], self.extra["shard_start"] = shard.total, shard.start
+            self.data = torch.rand((batch, n, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+            self.plans = [fa.Clcfft(local, n, True), fa.Clcfft(local, n, False)]
+            for p in self.plans:
+                assert p.get_error() == 0, p.get_log()
+            self.n = n
+            self.units = batch * n                       # complex samples per step per rank
+            self.alg_bytes = 16.0 * self.units           # SURVEY.md §8d: 8 B read + 8 B write per sample
+            self.step = lambda k: self.plans[k & 1].exec_device(self.data, batch, stream.cuda_stream)
+            self.workload = ("c2c N=65536 x %d batches per GPU, float32, in place, device-resident "
+                             "(BASELINE configs[1])" % batch)
+            self.kernel, self.tkey = self.plans[0].kernel_name(), "c2c65536"
+            self.metric = "Gsamples/s for batched 1D FFT (N=65536, float32) + achieved HBM GB/s vs peak"
+            self.direction = "steps alternate forward/inverse plans"
+        elif name == "rfft":
+            size, batch = 16384, batch_override or 8192
+            self.batch, self.n = batch, size
+            self.data = torch.rand((batch, size), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+            self.plans = [fa.Clrfft(local, size, True), fa.Clrfft(local, size, False)]
+            for p in self.plans:
+                assert p.get_error() == 0, p.get_log()
+            self.units = batch * size
+            self.alg_bytes = 8.0 * self.units            # 4 B real + 4 B packed complex per real sample, each way
+            self.step = lambda k: self.plans[k & 1].exec_device(self.data, batch, stream.cuda_stream)
+            self.workload = "r2c then c2r, size=16384 x %d batches per GPU, packed in place (BASELINE configs[2])" % batch
+            self.kernel, self.tkey = self.plans[0].kernel_name(), "rfft16384"
+            self.metric = "Gsamples/s (real samples) for batched r2c/c2r FFT size=16384"
+            self.direction = "steps alternate r2c / c2r plans"
+        else:
+            pts, cvs, ch = 1024, 96256, batch_override or 256
+            self.pc = pc = fa.Clpconv(local, cvs, pts, channels=ch)
+            assert pc.get_cl_err() == 0
+            ir = (torch.rand((ch, cvs), generator=g, device=dev) - 0.5) / (cvs ** 0.5)
+            assert pc.push_ir_device(ir) == 0
+            torch.cuda.synchronize()
+            self.inp = torch.rand((ch, pts), generator=g, device=dev) * 2 - 1
+            self.out = torch.empty((ch, pts), device=dev)
+            self.batch = ch
+            self.units = ch * pts                        # channel-samples per block
+            nparts = pc.nparts
+            self.alg_bytes = ch * (2.0 * nparts * pts * 8 + 4 * pts + 8 * pts + 4 * pts + 16 * pts)  # SURVEY.md §8d
+            self.step = lambda k: pc.process_device(self.out, self.inp, None, stream.cuda_stream)
+            self.workload = ("partitioned convolution, %d channels per GPU, pts=1024, IR 96256 (94 partitions), 48 kHz "
+                             "(BASELINE configs[3])" % ch)
+            self.kernel, self.tkey = "k_pconv_fused", "pconv1024x94"
+            self.metric = "channel-samples/s for partitioned convolution (x1e9)"
+            self.direction = "one block of 1024 samples per channel per step"
+        self.launches_before_timed = 0
+
+    def run(self, count):
+        """`count` untimed steps on the launch stream"""
+        for k in range(count):
+            assert self.step(k) == 0
+        self.launches_before_timed += count
+
+    def selfcheck(self):
+        """Full-size guard BEFORE the headline is timed (a broken kernel must not get a number): on the benchmark's
+        own buffer, at the benchmark's own size — the size-independent properties of the transform: round trip,
+        Parseval, linearity (c2c); round trip (packed real).  The data are restored bit for bit afterwards."""
+        if self.plans is None:
+            return None
+        torch, stream, data, batch, plans = self.torch, self.stream, self.data, self.batch, self.plans
+        checks = {}
+        with torch.cuda.stream(stream):
+            x0 = data.clone()
+            e0 = (x0.double() ** 2).sum()
+            assert plans[0].exec_device(data, batch, stream.cuda_stream) == 0          # forward (scaled 1/n)
+            launches = 2
+            if self.name == "c2c":
+                fx = data.clone()
+                checks["parseval_rel"] = abs(float(((fx.double() ** 2).sum() * self.n / e0).item()) - 1.0)
+            assert plans[1].exec_device(data, batch, stream.cuda_stream) == 0          # inverse
+            checks["roundtrip_max_abs"] = float((data - x0).abs().max().item())
+            if self.name == "c2c":
+                y = torch.rand(data.shape, generator=self.gen, device=data.device, dtype=torch.float32) * 2 - 1
+                z = 0.5 * x0 + y
+                assert plans[0].exec_device(y, batch, stream.cuda_stream) == 0
+                assert plans[0].exec_device(z, batch, stream.cuda_stream) == 0
+                launches += 2
+                z -= 0.5 * fx + y
+                checks["linearity_max_abs"] = float(z.abs().max().item())
+                checks["linearity_ref_max"] = float(fx.abs().max().item())
+                del fx, y, z
+            data.copy_(x0)
+            del x0
+            stream.synchronize()
+        assert checks["roundtrip_max_abs"] < 2e-5, checks          # |x| <= 1, float32, log2(n) = 16 stages each way
+        if self.name == "c2c":
+            assert checks["parseval_rel"] < 1e-5, checks
+            assert checks["linearity_max_abs"] < 1e-5 * max(checks["linearity_ref_max"], 1e-30) + 1e-7, checks
+        self.launches_before_timed += launches
+        checks["transform_launches"] = launches
+        return checks
+
+    def timed(self, K, barrier, series=False):
+        """K steps between one pair of HIP events on the launch stream and host clocks behind barrier +
+        synchronize on both sides -> (host seconds, mean ms per launch, per-launch ms or [])"""
+        torch, stream = self.torch, self.stream
+        with torch.cuda.stream(stream):
+            stream.synchronize()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            # One event pair for the whole region — an event after EVERY launch (--series-out) keeps the stream
+            # from running launches back to back and costs a 0.2 ms kernel 5-8 % (a 0.9 ms one 1-2 %).
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1 if series else 2)]
+            t0 = time.perf_counter()
+            ev[0].record(stream)
+            rc = 0
+            for k in range(K):
+                rc |= self.step(k)
+                if series:
+                    ev[k + 1].record(stream)
+            if not series:
+                ev[1].record(stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            barrier()
+        assert rc == 0
+        avg_ms = ev[0].elapsed_time(ev[-1]) / K
+        per = [ev[k].elapsed_time(ev[k + 1]) for k in range(K)] if series else []
+        self.launches_before_timed += K
+        return t1 - t0, avg_ms, per
+
+    def roofline(self, avg_ms):
+        achieved = self.alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic, source = traffic_from_profiles(self.tkey)
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+                "kernel": self.kernel, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": self.alg_bytes}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))          # nothing below has run: no torch import, no GPU call in this process
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -85,10 +263,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
-        a.gpus = world
+    a.gpus = world
+    if os.environ.get("CLFA_BENCH_REHEARSE") == "launch":
+        # tests only (tests/test_dist_cpu.py, no GPU there): the launch plumbing alone — ranks rendezvous over gloo,
+        # reduce like the real run does, rank 0 prints one line; no transform is run and no number is reported
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rehearsal": "launch", "n_gpus": world, "max_over_ranks": float(t.item()),
+                              "steps": a.steps, "warmup": a.warmup, "value": None}), flush=True)
+        dist.destroy_process_group()
+        return
     # rehearsal hooks (tests only): CLFA_BENCH_BACKEND=gloo CLFA_BENCH_DEVICE=0 run several ranks on ONE GPU
     backend = os.environ.get("CLFA_BENCH_BACKEND", "nccl")
     local = int(os.environ.get("CLFA_BENCH_DEVICE", local))
@@ -104,136 +291,75 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from opencl_fft_amd.dist import ShardedBatch
-
     def barrier():
         if world > 1:
             dist.barrier()
 
     stream = torch.cuda.Stream(device=dev)
     K, W = a.steps, a.warmup
-    extra = {}
+    wl = Workload(a.workload, fa, torch, dev, local, rank, world, a.batch, stream)
+    extra = wl.extra
 
-    if a.workload == "c2c":
-        n = 65536
-        # weak scaling: 4096 transforms per GPU (config 5 = 32768 over 8 GPUs); the global batch is
-        # split into contiguous blocks, rank r owns [start, start+count)
-        shard = ShardedBatch((a.batch or 4096) * world, rank, world)
-        batch = shard.count
-        extra["global_batch"], extra["shard_start"] = shard.total, shard.start
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        data = torch.rand((batch, n, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1
-        plans = [fa.Clcfft(local, n, True), fa.Clcfft(local, n, False)]
-        for p in plans:
-            assert p.get_error() == 0, p.get_log()
-        units = batch * n                       # complex samples per step per rank
-        alg_bytes = 16.0 * units                # 8 B read + 8 B write per sample
-        step = lambda k: plans[k & 1].exec_device(data, batch, stream.cuda_stream)
-        workload = "c2c N=65536 x %d batches per GPU, float32, in place, device-resident (BASELINE configs[1])" % batch
-        kernel, tkey = plans[0].kernel_name(), "c2c65536"
-        metric, unit = "Gsamples/s for batched 1D FFT (N=65536, float32) + achieved HBM GB/s vs peak", "Gsamples/s"
-    elif a.workload == "rfft":
-        size, batch = 16384, a.batch or 8192
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        data = torch.rand((batch, size), generator=g, device=dev, dtype=torch.float32) * 2 - 1
-        plans = [fa.Clrfft(local, size, True), fa.Clrfft(local, size, False)]
-        units = batch * size
-        alg_bytes = 8.0 * units                 # 4 B real + 4 B packed complex per real sample, each way
-        step = lambda k: plans[k & 1].exec_device(data, batch, stream.cuda_stream)
-        workload = "r2c then c2r, size=16384 x %d batches per GPU, packed in place (BASELINE configs[2])" % batch
-        kernel, tkey = plans[0].kernel_name(), "rfft16384"
-        metric, unit = "Gsamples/s (real samples) for batched r2c/c2r FFT size=16384", "Gsamples/s"
-    else:
-        pts, cvs, ch = 1024, 96256, a.batch or 256
-        pc = fa.Clpconv(local, cvs, pts, channels=ch)
-        assert pc.get_cl_err() == 0
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        ir = (torch.rand((ch, cvs), generator=g, device=dev) - 0.5) / (cvs ** 0.5)
-        assert pc.push_ir_device(ir) == 0
-        torch.cuda.synchronize()
-        inp = torch.rand((ch, pts), generator=g, device=dev) * 2 - 1
-        out = torch.empty((ch, pts), device=dev)
-        units = ch * pts                        # channel-samples per block
-        nparts = pc.nparts
-        alg_bytes = ch * (2.0 * nparts * pts * 8 + 4 * pts + 8 * pts + 4 * pts + 16 * pts)
-        step = lambda k: pc.process_device(out, inp, None, stream.cuda_stream)
-        workload = ("partitioned convolution, %d channels per GPU, pts=1024, IR 96256 (94 partitions), 48 kHz "
-                    "(BASELINE configs[3])" % ch)
-        kernel, tkey = "k_pconv_fused", "pconv1024x94"
-        metric, unit = "channel-samples/s for partitioned convolution (x1e9)", "Gsamples/s"
-
-    # Full-size guard BEFORE anything is timed (a broken kernel must not get a number): on the benchmark's own
-    # buffer, at the benchmark's own size — the size-independent properties of the transform: round trip,
-    # Parseval, linearity (c2c); round trip (packed real).  ~15 launch-equivalents of device work; the data are
-    # restored bit for bit afterwards.  (Side effect, stated in DESIGN.md section 5: the chip's ~20 ms start-up
-    # clock ramp is over when the W warm-up steps begin.)
-    if a.workload in ("c2c", "rfft") and not a.no_selfcheck:
+    # 1. the contract's reading taken cold: W warm-up steps, K timed steps, nothing before them
+    cold = None
+    if not a.no_cold and not a.series_out:
         with torch.cuda.stream(stream):
-            x0 = data.clone()
-            e0 = (x0.double() ** 2).sum()
-            assert plans[0].exec_device(data, batch, stream.cuda_stream) == 0          # forward (scaled 1/n)
-            checks = {}
-            if a.workload == "c2c":
-                fx = data.clone()
-                checks["parseval_rel"] = abs(float(((fx.double() ** 2).sum() * n / e0).item()) - 1.0)
-            assert plans[1].exec_device(data, batch, stream.cuda_stream) == 0          # inverse
-            checks["roundtrip_max_abs"] = float((data - x0).abs().max().item())
-            if a.workload == "c2c":
-                y = torch.rand(data.shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1
-                z = 0.5 * x0 + y
-                assert plans[0].exec_device(y, batch, stream.cuda_stream) == 0
-                assert plans[0].exec_device(z, batch, stream.cuda_stream) == 0
-                z -= 0.5 * fx + y
-                checks["linearity_max_abs"] = float(z.abs().max().item())
-                checks["linearity_ref_max"] = float(fx.abs().max().item())
-                del fx, y, z
-            data.copy_(x0)
-            del x0
-            stream.synchronize()
-        assert checks["roundtrip_max_abs"] < 2e-5, checks          # |x| <= 1, float32, log2(n) = 16 stages each way
-        if a.workload == "c2c":
-            assert checks["parseval_rel"] < 1e-5, checks
-            assert checks["linearity_max_abs"] < 1e-5 * max(checks["linearity_ref_max"], 1e-30) + 1e-7, checks
-        extra["full_size_selfcheck"] = checks
-
+            wl.run(W)
+        cold_s, cold_ms, _ = wl.timed(K, barrier)
+        cold = {"ms_per_step": cold_s / K * 1e3, "avg_launch_ms": cold_ms}
+    # 2. the full-size guard (~15 launch-equivalents of device work with its elementwise kernels)
+    if not a.no_selfcheck:
+        chk = wl.selfcheck()
+        if chk is not None:
+            extra["full_size_selfcheck"] = chk
+    # 3. the headline: W warm-up steps, K timed steps — by now past the chip's start-up clock ramp
     with torch.cuda.stream(stream):
-        for k in range(W):
-            assert step(k) == 0
-        stream.synchronize()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        # HIP events on the launch stream bracket the K launches: roofline.achieved divides by their mean.
-        # One event pair for the whole region — an event after EVERY launch (--series-out) keeps the stream
-        # from running launches back to back and costs a 0.2 ms kernel 5-8 % (a 0.9 ms one 1-2 %).
-        series = bool(a.series_out)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1 if series else 2)]
-        t0 = time.perf_counter()
-        ev[0].record(stream)
-        for k in range(K):
-            rc = step(k)
-            if series:
-                ev[k + 1].record(stream)
-        if not series:
-            ev[1].record(stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        barrier()
-    assert rc == 0
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+        wl.run(W)
+    extra["effective_warmup_launches"] = wl.launches_before_timed
+    elapsed, avg_ms, per_launch_ms = wl.timed(K, barrier, series=bool(a.series_out))
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-    avg_ms = ev[0].elapsed_time(ev[-1]) / K          # mean launch duration over the timed region (both directions)
-    per_launch_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(K)] if series else []
-    if series and a.workload != "pconv" and K > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if cold is not None:
+        cm = torch.tensor([cold["ms_per_step"]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(cm, op=dist.ReduceOp.MAX)
+        cold["ms_per_step"] = float(cm.item())
+    if per_launch_ms and a.workload != "pconv" and K > 1:
         fwd_ms, inv_ms = per_launch_ms[0::2], per_launch_ms[1::2]
         extra["launch_ms"] = {"fwd_avg": sum(fwd_ms) / len(fwd_ms), "fwd_min": min(fwd_ms), "fwd_max": max(fwd_ms),
                               "inv_avg": sum(inv_ms) / len(inv_ms), "inv_min": min(inv_ms), "inv_max": max(inv_ms)}
 
+    # 4. configs[2] and configs[3] in the same run (N = 1 only: the multi-GPU line stays the sharded headline)
+    others = None
+    if world == 1 and not a.no_other_workloads and not a.series_out and a.batch == 0:
+        others = {}
+        for name in ("c2c", "rfft", "pconv"):
+            if name == a.workload:
+                continue
+            o = Workload(name, fa, torch, dev, local, rank, world, 0, stream)
+            k2, w2 = max(K, 100), max(W, 20)
+            with torch.cuda.stream(stream):
+                o.run(w2)
+            chk = None if a.no_selfcheck else o.selfcheck()
+            with torch.cuda.stream(stream):
+                o.run(w2)
+            s2, ms2, _ = o.timed(k2, barrier)
+            rec = {"workload": o.workload, "metric": o.metric, "value": o.units * k2 / s2 / 1e9, "unit": "Gsamples/s",
+                   "steps": k2, "warmup": w2, "effective_warmup_launches": o.launches_before_timed - k2,
+                   "ms_per_step": s2 / k2 * 1e3, "direction": o.direction, "roofline": o.roofline(ms2)}
+            if chk is not None:
+                rec["full_size_selfcheck"] = chk
+            if name == "pconv":
+                rec["realtime_ratio"] = (1024 / 48000.0) / (ms2 * 1e-3)   # one block = pts / 48 kHz of audio per channel
+            others[name] = rec
+            del o
+            torch.cuda.empty_cache()
+
     # The yardsticks the roofline fraction is read against: sustained device
     # read / write / copy bandwidth, and a copy in the FFT's own access shape (column blocks of 16
-    # columns), measured here, on this device, AFTER the timed region (run before it, 150 ms of copy
+    # columns), measured here, on this device, AFTER the timed regions (run before them, 150 ms of copy
     # kernels leave the chip in a lower clock state and the first ~20 FFT launches read 5-15 % slower).
     membench = None
     if not a.no_bandwidth and rank == 0:
@@ -244,7 +370,7 @@ def main():
                            "copies count read + write; copy_colblock = 128-byte row segments 2 KiB apart (the "
                            "four-step FFT's global access shape)")
     # parity guard, AFTER the timed region (the oracle's OpenMP pool must not be spinning on the
-    # host cores while the HIP runtime threads drive the timed launches): one transform vs the oracle
+    # host cores while the HIP runtime threads drive the timed launches): transforms vs the oracle
     if a.workload == "c2c":
         from oracle import oracle
         gq = torch.Generator(device=dev).manual_seed(99)
@@ -254,7 +380,7 @@ def main():
         x0 = probe[pick].cpu().numpy().view(np.complex64).reshape(len(pick), 65536)
         # (the INVERSE plan: a different kernel instantiation than the forward one whose launches the
         # roofline block and the rocprofv3 stats average, so this short launch does not dilute them)
-        assert plans[1].exec_device(probe, nprobe, stream.cuda_stream) == 0
+        assert wl.plans[1].exec_device(probe, nprobe, stream.cuda_stream) == 0
         stream.synchronize()
         y0 = probe[pick].cpu().numpy().view(np.complex64).reshape(len(pick), 65536)
         ref = oracle.cfft(x0, False, nthreads=1)
@@ -263,31 +389,35 @@ def main():
         assert extra["parity_relL2_vs_oracle"] < 1e-6
 
     # end-of-run checksum over all ranks (validates the sharded run; RCCL only here)
-    chk = (data.double() ** 2).sum().reshape(1) if a.workload != "pconv" else (out.double() ** 2).sum().reshape(1)
+    chk = (wl.data.double() ** 2).sum().reshape(1) if a.workload != "pconv" else (wl.out.double() ** 2).sum().reshape(1)
     if world > 1:
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)
     extra["energy_checksum_all_ranks"] = float(chk.item())
 
     if rank == 0:
-        value = units * K * world / elapsed / 1e9
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        value = wl.units * K * world / elapsed / 1e9
         rec = {
-            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": K, "warmup": W,
+            "metric": wl.metric, "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": dict({"workload": workload, "direction": "steps alternate forward/inverse plans",
-                            "sharding": "batches per rank, no data-path collective", "kernel": kernel,
+            "config": dict({"workload": wl.workload, "direction": wl.direction,
+                            "sharding": "batches per rank, no data-path collective", "kernel": wl.kernel,
                             }, **extra),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(tkey),
-                         "kernel": kernel, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline": wl.roofline(avg_ms),
         }
+        if cold is not None:
+            # the contract's W + K launches read cold (before the self-check): inside the chip's start-up clock ramp
+            rec["ms_per_step_cold"] = cold["ms_per_step"]
+            rec["roofline"]["avg_launch_ms_cold"] = cold["avg_launch_ms"]
+            rec["roofline"]["frac_cold"] = wl.alg_bytes / (cold["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if others is not None:
+            rec["config"]["other_workloads"] = others
         if membench is not None:
             rec["membench"] = membench
             # the same achieved rate against what this device sustains for a plain copy and for a copy
             # in the FFT's access shape (8000 GB/s, the peak of the roofline block, is the HBM3E spec)
-            rec["roofline"]["frac_of_measured_copy"] = achieved / (membench["copy"] * 1e3)
-            rec["roofline"]["frac_of_measured_colblock_copy"] = achieved / (membench["copy_colblock"] * 1e3)
+            rec["roofline"]["frac_of_measured_copy"] = rec["roofline"]["achieved"] / (membench["copy"] * 1e3)
+            rec["roofline"]["frac_of_measured_colblock_copy"] = rec["roofline"]["achieved"] / (membench["copy_colblock"] * 1e3)
         if a.workload == "pconv":
             # one block = pts / 48 kHz of audio for every channel
             rec["config"]["realtime_ratio"] = (1024 / 48000.0) / (avg_ms * 1e-3)

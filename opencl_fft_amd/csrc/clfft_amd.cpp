@@ -76,15 +76,30 @@ struct DeviceGuard {
 struct StreamOrder {
   hipStream_t last = nullptr;
   bool any = false;
+  static bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+      (void)hipGetLastError();   // a stale handle: not capturing
+      return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+  }
   hipError_t use(hipStream_t s) {
     hipError_t e = hipSuccess;
     if (any && s != last) {
       // a stream under hipGraph capture must not be waited for (nor may anything else be while it
       // captures): captured launches are ordered by the graph, and whatever the object was doing
-      // before the capture has to be complete when the graph is replayed — the caller's contract
-      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(s, &st) != hipSuccess) (void)hipGetLastError();
-      if (st == hipStreamCaptureStatusNone) e = hipStreamSynchronize(last);
+      // before the capture has to be complete when the graph is replayed — the caller's contract.
+      // The same holds when the PREVIOUS stream is the one under capture.
+      if (!capturing(s) && !capturing(last)) {
+        e = hipStreamSynchronize(last);
+        if (e == hipErrorInvalidHandle || e == hipErrorContextIsDestroyed || e == hipErrorInvalidResourceHandle) {
+          // the caller has destroyed its previous stream (we do not own it and cannot keep it alive): its handle is
+          // gone, its work may not be — wait for the device instead of the handle, and carry on
+          (void)hipGetLastError();
+          e = hipDeviceSynchronize();
+        }
+      }
     }
     last = s;
     any = true;

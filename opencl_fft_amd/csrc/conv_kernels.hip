@@ -218,7 +218,7 @@ int pconv_mac_split(const PconvGeom &g) {
   static const int cap = [] {
     const char *e = getenv("CLFA_PCONV_SPLIT_MAX");
     const int v = e ? atoi(e) : 512;
-    return v < 1 ? 1 : v;
+    return v < 1 ? 1 : (v > 2048 ? 2048 : v);   // the two-level sum holds 64 groups of 32 partial accumulators
   }();
   long lanes = (long)g.channels * (g.bins / 2);
   const long target = lanes <= 1024 ? 128L * 1024 : 64L * 1024;   // measured: the finer split pays up to pts = 2048
@@ -242,23 +242,23 @@ hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *rin
   if (e != hipSuccess || nsplit == 1 || !reduce) return e;
   long total2 = total * 2, rgrid = (total2 + 255) / 256;
   if (rgrid > 4096) rgrid = 4096;
-  auto sum = [&](int groups, int count, int stride) {   // the smallest unrolled form that holds `count`
+  auto sum = [&](int groups, int count, int stride) -> hipError_t {   // the smallest unrolled form that holds `count`
     const dim3 grid((int)rgrid, groups), block(256);
+    if (count > 64) return hipErrorInvalidValue;   // (cannot happen below the 2048 cap: a dropped partial sum must not pass silently)
     if (count <= 2) hipLaunchKernelGGL(k_pconv_reduce<2>, grid, block, 0, s, acc, total2, nsplit, count, stride);
     else if (count <= 4) hipLaunchKernelGGL(k_pconv_reduce<4>, grid, block, 0, s, acc, total2, nsplit, count, stride);
     else if (count <= 8) hipLaunchKernelGGL(k_pconv_reduce<8>, grid, block, 0, s, acc, total2, nsplit, count, stride);
     else if (count <= 16) hipLaunchKernelGGL(k_pconv_reduce<16>, grid, block, 0, s, acc, total2, nsplit, count, stride);
     else if (count <= 32) hipLaunchKernelGGL(k_pconv_reduce<32>, grid, block, 0, s, acc, total2, nsplit, count, stride);
     else hipLaunchKernelGGL(k_pconv_reduce<64>, grid, block, 0, s, acc, total2, nsplit, count, stride);
+    return hipGetLastError();
   };
   if (nsplit > 64) {   // groups of 32, then the group sums
     const int groups = (nsplit + 31) / 32;
-    sum(groups, 32, 1);
-    sum(1, groups, 32);
-  } else {
-    sum(1, nsplit, 1);
+    if ((e = sum(groups, 32, 1)) != hipSuccess) return e;
+    return sum(1, groups, 32);
   }
-  return hipGetLastError();
+  return sum(1, nsplit, 1);
 }
 
 // ---------------------------------------------------------------------------------

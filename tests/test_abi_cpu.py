@@ -98,8 +98,12 @@ def test_resident_kernel_code_object_audit(tmp_path):
             flags = ln.split("=", 1)[1].replace("$(ARCH)", "gfx950").split()
     assert flags, "CXXFLAGS not found in the Makefile"
     obj = str(tmp_path / "fft_resident.o")
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-save-temps=obj", "-c", src, "-o", obj],
-                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine: the code-object audit needs the gfx950 cross-compiler")
+    p = subprocess.run([hipcc] + flags + ["-save-temps=obj", "-c", src, "-o", obj], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
     asm = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
     assert len(asm) == 1, asm
     spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))

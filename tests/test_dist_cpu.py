@@ -164,3 +164,31 @@ def test_eight_rank_gloo_product_path(tmp_path, total):
         assert m[1] == 0.5 + 0.25 * (world - 1)               # max over ranks
         assert (int(m[2]), int(m[3])) == shard_range(total, r, world)
         assert int(m[5]) == int(m[3]) and int(m[4]) == (1 if m[3] else 0)   # one launch over the rank's own batches
+
+
+def test_bench_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no outer launcher (WORLD_SIZE unset): bench.py starts torch.distributed.run as a
+    child before it imports torch, the two ranks rendezvous over gloo on 127.0.0.1, rank 0 alone prints the line and
+    the parent exits with the children's code.  (CLFA_BENCH_REHEARSE=launch: the plumbing only — there is no GPU here,
+    and the product path has no CPU fallback to rehearse with.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CLFA_BENCH_REHEARSE"] = "launch"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["max_over_ranks"] == 2.0 and r["steps"] == 3 and r["warmup"] == 1
+    # failing ranks must fail the parent: without the rehearsal switch the ranks need a GPU, and there is none here
+    import torch
+    if torch.cuda.device_count() == 0:
+        del env["CLFA_BENCH_REHEARSE"]
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode != 0
+        assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]

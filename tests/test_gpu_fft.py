@@ -147,6 +147,53 @@ def test_cfft_resident_kernel_both_directions():
         assert_parity(y, oracle.cfft(x, fwd), what="resident kernel fwd=%s" % fwd)
 
 
+@pytest.mark.parametrize("n", [16384, 32768, 65536])
+def test_cfft_batched_kernels_vs_reference_vectors(n):
+    """The reference's own outputs (Clcfft::transform, cl_fft.cpp:153-161, run on the MI355X through OpenCL) against the
+    BATCHED kernels: a single transform of these lengths goes to the column / row kernel pair, so the golden input
+    LCG(12345) is replicated 70 times — the batch that selects k_fft_res16 (n = 65536) resp. the persistent four-step
+    kernel — and EVERY transform of the batch is compared with the reference's vector."""
+    batch = 70
+    x = np.tile(util.lcg_complex(12345, n), (batch, 1))
+    for fwd in (True, False):
+        plan = fa.Clcfft(0, n, fwd)
+        assert plan.kernel_name() == ("k_fft_res16" if n == 65536 else "k_fft_4step")
+        y = x.copy()
+        assert plan.transform(y) == 0
+        ref = golden("g4_cfft%d_%s_dec" % (n, "fwd" if fwd else "inv"))
+        for b in range(batch):
+            assert_parity(util.decimate(y[b]), ref, what="n=%d fwd=%s transform %d vs reference" % (n, fwd, b))
+        assert np.array_equal(y.view(np.uint32), np.tile(y[0], (batch, 1)).view(np.uint32)), "transforms of one batch differ"
+
+
+@pytest.mark.parametrize("size", [32768, 65536, 131072])
+def test_rfft_batched_kernels_vs_reference_vectors(size):
+    """Clrfft::transform (cl_fft.cpp:267-296) vectors against the one-pass real kernels: more than 32 transforms select
+    k_fft_lds<14> (size 32768) / k_rfft_lds15 (size 65536) instead of the spread path a single transform takes; every
+    transform of the batch against the reference's forward, round-trip and arbitrary-spectrum inverse vectors, bin M/2
+    (the reference's never-conjugated self-paired bin, cl_fft.cpp:278) included."""
+    batch, m = 70, size // 2
+    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+    if size <= 65536:
+        assert f.kernel_name() == ("k_rfft_lds15" if size == 65536 else "k_fft_lds")
+    x = np.tile(util.lcg_sym(12345, size), (batch, 1))
+    buf = x.copy().view(np.complex64)
+    assert f.transform(buf) == 0                                   # in place, batch x m packed bins
+    ref = golden("g5_rfft%d_fwd_dec" % size)
+    for b in range(batch):
+        got = np.concatenate([util.decimate(buf[b]), buf[b, m // 2:m // 2 + 1]])
+        assert_parity(got, ref, what="size=%d fwd transform %d" % (size, b))
+    assert i.transform(buf) == 0
+    ref = golden("g5_rfft%d_rt_dec" % size)
+    for b in range(batch):
+        assert_parity(util.decimate(buf[b]), ref, what="size=%d round trip %d" % (size, b))
+    arb = np.tile(util.lcg_complex(777, m), (batch, 1))
+    assert i.transform(arb) == 0
+    ref = golden("g5_rfft%d_invarb_dec" % size)
+    for b in range(batch):
+        assert_parity(util.decimate(arb[b]), ref, what="size=%d invarb %d" % (size, b))
+
+
 @pytest.mark.parametrize("n,batch", [(16384, 70), (16384, 300), (32768, 70), (32768, 300), (65536, 70), (65536, 300)])
 def test_cfft_persistent_kernel_ragged(n, batch):
     """the persistent four-step kernel (intermediate in LDS + registers) with batch counts that are

@@ -163,3 +163,30 @@ def test_plan_on_two_streams_is_ordered():
     for d in (d1, d2):
         got = d.cpu().numpy().view(np.complex64).reshape(batch, n)[::7]
         util.assert_parity(got, want, what="two streams")
+
+
+def test_plan_survives_a_destroyed_caller_stream():
+    """the caller's previous stream is not the library's to keep alive: use stream A, destroy it, then call on stream B
+    (and on the host entry point, which runs on the plan's own stream) — no spurious failure, right results"""
+    import ctypes
+    import torch
+    n, batch = 32768, 96
+    x = util.lcg_complex(6, n * batch).reshape(batch, n)
+    hip = ctypes.CDLL("libamdhip64.so")
+    plan = fa.Clcfft(0, n, True)
+    d1 = torch.from_numpy(x.view(np.float32).copy()).cuda()
+    d2 = d1.clone()
+    torch.cuda.synchronize()
+    sa = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(sa)) == 0
+    assert plan.exec_device(d1, batch, sa.value) == 0
+    assert hip.hipStreamDestroy(sa) == 0
+    sb = torch.cuda.Stream()
+    assert plan.exec_device(d2, batch, sb.cuda_stream) == 0
+    torch.cuda.synchronize()
+    y = x[:3].copy()
+    assert plan.transform(y) == 0                       # host entry point: the plan's own stream
+    want = oracle.cfft(x[::7], True)
+    for d in (d1, d2):
+        assert_parity(d.cpu().numpy().view(np.complex64).reshape(batch, n)[::7], want, what="after stream destroy")
+    assert_parity(y, oracle.cfft(x[:3], True), what="host call after stream destroy")

@@ -15,6 +15,7 @@ import re
 import sys
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+AREG = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
 RESERVED_FIRST = 224   # v[224:255]: landing registers of asm-issued loads (kernel built with amdgpu_num_vgpr(224))
 
 
@@ -46,7 +47,46 @@ def audit_reserved(body):
         hit = [r for r in regs_of(code) if r >= RESERVED_FIRST]
         if hit:
             problems.append("compiler instruction touches reserved v%s: %s" % (sorted(hit), code.strip()))
+        # on gfx90a+ the allocator may name an AGPR directly as an operand (AV register class: ds_*, buffer_*,
+        # v_mov ...) without any v_accvgpr_* instruction: the whole accumulation file is the kernel's own
+        if AREG.search(code.split(None, 1)[1] if " " in code.strip() or "\t" in code.strip() else ""):
+            problems.append("compiler instruction names an AGPR: %s" % code.strip())
     return problems
+
+
+def audit_loop_loads(body):
+    """the explicit s_waitcnt vmcnt(N) scheme counts the asm-issued loads only: a compiler-issued global / buffer
+    LOAD anywhere after the table prologue would shift every count.  Compiler-issued stores only make a wait
+    stronger and are allowed (the slot's write-through store, the last block's burst)."""
+    problems = []
+    inasm = False
+    seen_barrier = False
+    for ln in body.split("\n"):
+        s = ln.strip()
+        if "ASMSTART" in s:
+            inasm = True
+            continue
+        if "ASMEND" in s:
+            inasm = False
+            continue
+        if inasm or not s or s.startswith((";", ".")):
+            continue
+        code = s.split(";")[0].strip()
+        if code.startswith("s_barrier"):
+            seen_barrier = True
+        if seen_barrier and re.match(r"(buffer|global|flat)_load", code):
+            problems.append("compiler-issued vector load behind the prologue: %s" % code)
+    return problems
+
+
+def metadata_of(s, name):
+    """.amdhsa / amdhsa.kernels metadata of one kernel -> dict of the integer fields"""
+    m = re.search(r"- \.agpr_count:.*?\.name:\s+%s\b.*?(?=\n  - \.agpr_count:|\n\.\.\.|\Z)" % re.escape(name), s, re.S)
+    out = {}
+    if m:
+        for k, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", m.group(0), re.M):
+            out[k] = int(v)
+    return out
 
 
 def check(path):
@@ -71,8 +111,15 @@ def check(path):
             problems.append("%s: %d compiler-generated AGPR moves" % (name, stray))
         if re.search(r"\bscratch_(load|store)", body):
             problems.append("%s: scratch memory accesses" % name)
-        for p in audit_reserved(body):
+        for p in audit_reserved(body) + audit_loop_loads(body):
             problems.append("%s: %s" % (name, p))
+        md = metadata_of(s, name)
+        if not md:
+            problems.append("%s: no kernel metadata found" % name)
+        else:
+            for key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count"):
+                if md.get(key, 0) != 0:
+                    problems.append("%s: %s = %d" % (name, key, md[key]))
     if not found:
         problems.append("no k_fft_res16 kernel in %s" % path)
     return problems
