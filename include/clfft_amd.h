@@ -144,6 +144,9 @@ CLFA_API int clfa_pconv_convolution_tv(clfa_pconv *pc, float *out, const float *
 /* device-resident variants; in2 may be NULL (static IR) */
 CLFA_API int clfa_pconv_process_dev(clfa_pconv *pc, void *out, const void *in1, const void *in2, void *stream);
 CLFA_API size_t clfa_pconv_state_bytes(const clfa_pconv *pc);
+/* which launch structure a block of this object takes (diagnostics and tests): "k_pconv_fused" (one launch, one
+ * workgroup per channel), "k_pconv_coop" (one launch, a few channels), "chain" (forward / MAC / inverse launches) */
+CLFA_API const char *clfa_pconv_kernel_name(const clfa_pconv *pc);
 
 /* ---- direct convolution: cl_conv::Cldconv ----------------------------------- */
 /* Cldconv::Cldconv(device_id, cvs, vsize, ...), cl_dconv.cpp:46-98 */

@@ -227,6 +227,9 @@ class Clpconv:
     def state_bytes(self):
         return lib().clfa_pconv_state_bytes(self._h)
 
+    def kernel_name(self):
+        return lib().clfa_pconv_kernel_name(self._h).decode()
+
     def push_ir(self, ir):
         """cl_conv.cpp:353-388; ir: float32[channels, nparts*pts] (or 1-D for one channel)"""
         ir = np.ascontiguousarray(ir, dtype=np.float32)

@@ -44,6 +44,7 @@ SYMBOLS = [
     ("clfa_pconv_convolution_tv", C.c_int, [_vp, _vp, _vp, _vp]),
     ("clfa_pconv_process_dev", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("clfa_pconv_state_bytes", C.c_size_t, [_vp]),
+    ("clfa_pconv_kernel_name", C.c_char_p, [_vp]),
     ("clfa_dconv_create", C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),
     ("clfa_dconv_destroy", None, [_vp]),
     ("clfa_dconv_get_error", C.c_int, [_vp]),

@@ -564,6 +564,289 @@ hipError_t launch_pconv_fused(const PconvGeom &g, const float *in1, const float 
 }
 
 // ---------------------------------------------------------------------------------
+// cooperative block: ONE launch per block for a FEW channels — the single-instance call that the reference's
+// opcodes and its own harness make (cl_conv.cpp:393-458 / 460-548 once per ksmps block; csound/tests.py:22-29).
+// With one channel the chain above is four or five dependent launches of 5 us each.  Here S workgroups per
+// channel split the BIN axis of the multiply-accumulate (no partial sums to add up: a bin's whole sum over the
+// partitions is formed inside one workgroup, rows of lanes walking the partitions in parallel and meeting in
+// LDS in fixed order), every workgroup transforms the new input block itself (a few microseconds of redundant
+// arithmetic instead of a grid-wide hand-over of the new frame; workgroup 0 also files it in the ring for the
+// blocks to come), and the only inter-workgroup step is the hand-over of the finished accumulator slices —
+// bins x 8 bytes per channel in all — to whichever workgroup arrives LAST at the channel's counter: it runs the
+// inverse chain.  No workgroup ever waits for another one: nothing spins.
+// Hand-over protocol (MI355X_MICROARCH.md, "Valid forms"): slices stored with agent-scope (sc1) stores, every
+// storing wave s_waitcnt vmcnt(0), workgroup barrier, ONE lane's agent-scope atomic add on the channel's counter;
+// the workgroup whose add returns S - 1 reads every slice with agent-scope (sc1) loads after its own barrier.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void st_agent(cpx *p, cpx v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ cpx ld_agent(const cpx *p) {
+  return __builtin_bit_cast(cpx, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int LOGB, bool TV>
+__global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in1, const float *__restrict__ in2,
+                                                    cpx *__restrict__ ringA, cpx *__restrict__ ringB,
+                                                    float *__restrict__ tail, float *__restrict__ out, int frame1,
+                                                    int frame2, int wp, int nparts, const cpx *__restrict__ tab_g,
+                                                    const cpx *__restrict__ w2f_g, const cpx *__restrict__ w2i_g,
+                                                    cpx *__restrict__ xacc, unsigned *__restrict__ counters, int logs) {
+  using G = LdsGeom<LOGB>;
+  constexpr int N = G::N, E = G::E, T = G::T, HB = N / 2;   // N = bins; T = N/16 lanes run the FFTs
+  static_assert(T <= 256 && N / 2 >= 256, "bins 512..4096");
+  __shared__ cpx s_tab[G::HALF];
+  __shared__ cpx s_x[G::PADN];
+  __shared__ cpx s_fa[N];               // packed spectrum of the new input block (frame1 of ring A)
+  __shared__ cpx s_fb[TV ? N : 1];      // ... of the second input (frame2 of ring B)
+  __shared__ cpx2 s_red[256];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int ch = blockIdx.y, sl = blockIdx.x, S = 1 << logs;
+  for (int i = tid; i < N / 2; i += 256) s_tab[i] = tab_g[i];
+  __syncthreads();
+
+  // ---- forward chain(s) in every workgroup: reference reorder + fft + r2c (cl_conv.cpp:399-419 / 465-513) ----
+  auto forward = [&](const float *in, cpx *ring, int frame, cpx *sf) {
+    cpx v[E];
+    if (tid < T) {
+      const cpx *src = reinterpret_cast<const cpx *>(in + (long)ch * N);
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int p = tid + T * e;
+        v[e] = p < N / 2 ? src[p] : mk(0.f, 0.f);
+      }
+      pass_compute<LOGB, G::LOGE, 0, true>(v, tid, s_tab);
+    }
+    __syncthreads();
+    if (tid < T) pass_scatter<LOGB, G::LOGE, 0>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+    __syncthreads();
+    if (tid < T) {
+      pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+      pass_compute<LOGB, G::LOGE, 4, true>(v, tid, s_tab);
+    }
+    if constexpr (LOGB > 8) {
+      __syncthreads();
+      if (tid < T) pass_scatter<LOGB, G::LOGE, 4>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+      __syncthreads();
+      if (tid < T) {
+        pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+        pass_compute<LOGB, G::LOGE, 8, true>(v, tid, s_tab);
+      }
+    }
+    __syncthreads();
+    if (tid < T) {
+#pragma unroll
+      for (int e = 0; e < E; e++) s_x[lds_pad(tid + T * e)] = v[e];
+    }
+    __syncthreads();
+    cpx *x = ring + ((long)ch * nparts + frame) * N;
+    for (int i = tid; i < N / 2; i += 256) {
+      const int j = i == 0 ? N / 2 : N - i;
+      const cpx ci = s_x[lds_pad(i)], cj = s_x[lds_pad(j)];
+      cpx oi, oj;
+      r2c_pair(ci, cj, w2f_g[i], oi, oj);
+      if (i == 0) {
+        oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
+        oj = cj;
+      }
+      sf[i] = oi;
+      sf[j] = oj;
+      if (sl == 0) {   // filed in the ring for the blocks to come; nobody reads it from there in this launch
+        x[i] = oi;
+        x[j] = oj;
+      }
+    }
+    __syncthreads();
+  };
+  forward(in1, ringA, frame1, s_fa);
+  if constexpr (TV) forward(in2, ringB, frame2, s_fb);
+
+  // ---- MAC over all partitions for this workgroup's slice of the bins (reference convol, cl_conv_kernels.h:102-118)
+  // slice = N >> logs bins = IW 16-byte items; lane = item li of partition row pr; rows walk p = pr, pr + NR, ...
+  {
+    const int iw = HB >> logs, nr = 256 / iw;
+    const int li = tid % iw, pr = tid / iw;
+    const int item = sl * iw + li;                       // 16-byte item (bins 2 item, 2 item + 1) of the frame
+    const cpx2 *a = reinterpret_cast<const cpx2 *>(ringA + (long)ch * nparts * N) + item;
+    const cpx2 *b = reinterpret_cast<const cpx2 *>(ringB + (long)ch * nparts * N) + item;
+    const bool dc = item == 0;                           // packed DC / Nyquist bin: (re*re, im*im)
+    cpx s0 = mk(0.f, 0.f), s1 = mk(0.f, 0.f);
+    auto term = [&](const cpx2 &av, const cpx2 &bv, bool live) {
+      cpx pa = cmul_plain(av.a, bv.a);
+      pa = mk(dc ? av.a.x * bv.a.x : pa.x, dc ? av.a.y * bv.a.y : pa.y);
+      const cpx pb = cmul_plain(av.b, bv.b);
+      s0 = cadd(s0, mk(live ? pa.x : 0.f, live ? pa.y : 0.f));
+      s1 = cadd(s1, mk(live ? pb.x : 0.f, live ? pb.y : 0.f));
+    };
+    // the frames written by THIS launch (frame1 of A; frame2 of B) are taken from LDS below: in the loop their
+    // (stale) ring contents are read like any other frame and dropped by a select — no branch in the stream
+    const int p1 = nparts - 1;                           // (wp + p1) % nparts == frame1: wp = frame1 + 1
+    constexpr int UNR = 4;
+    int p = pr;
+    for (; p + (UNR - 1) * nr < nparts; p += UNR * nr) {
+      cpx2 av[UNR], bv[UNR];
+      bool live[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const int pp = p + u * nr;
+        int fr = wp + pp;
+        fr = fr < nparts ? fr : fr - nparts;
+        av[u] = ld_stream(a + (long)fr * HB);
+        bv[u] = ld_stream(b + (long)pp * HB);
+        live[u] = pp != p1 && !(TV && pp == frame2);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) term(av[u], bv[u], live[u]);
+    }
+    for (; p < nparts; p += nr) {
+      int fr = wp + p;
+      fr = fr < nparts ? fr : fr - nparts;
+      term(ld_stream(a + (long)fr * HB), ld_stream(b + (long)p * HB), p != p1 && !(TV && p == frame2));
+    }
+    // the terms of the new frames, by the row that owns their partition
+    const cpx2 *fa = reinterpret_cast<const cpx2 *>(s_fa) + item;
+    if (pr == p1 % nr) {
+      cpx2 bv;
+      if (TV && p1 == frame2) bv = reinterpret_cast<const cpx2 *>(s_fb)[item];
+      else bv = b[(long)p1 * HB];
+      term(*fa, bv, true);
+    }
+    if constexpr (TV) {
+      if (frame2 != p1 && pr == frame2 % nr) {
+        int fr = wp + frame2;
+        fr = fr < nparts ? fr : fr - nparts;
+        term(a[(long)fr * HB], reinterpret_cast<const cpx2 *>(s_fb)[item], true);
+      }
+    }
+    cpx2 mine;
+    mine.a = s0;
+    mine.b = s1;
+    s_red[tid] = mine;
+    __syncthreads();
+    if (pr == 0) {   // rows summed in ascending order: deterministic
+      cpx t0 = s_red[li].a, t1 = s_red[li].b;
+      for (int r = 1; r < nr; r++) {
+        t0 = cadd(t0, s_red[r * iw + li].a);
+        t1 = cadd(t1, s_red[r * iw + li].b);
+      }
+      cpx *dst = xacc + (long)ch * N + 2 * item;
+      st_agent(dst, t0);
+      st_agent(dst + 1, t1);
+    }
+  }
+  // ---- hand-over: the last workgroup to arrive at the channel's counter owns the inverse chain
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(counters + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == (unsigned)(S - 1);
+    if (s_last) __hip_atomic_store(counters + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  // ---- inverse chain: c2r + inverse FFT + overlap-add (cl_conv_kernels.h:87-100, 120-124) -------------
+  const cpx *xa = xacc + (long)ch * N;
+  for (int i = tid; i < N / 2; i += 256) {
+    if (i == 0) {
+      const cpx c0 = ld_agent(xa);
+      s_x[0] = mk(c0.x + c0.y, c0.x - c0.y);
+      s_x[lds_pad(N / 2)] = ld_agent(xa + N / 2);
+    } else {
+      cpx oi, oj;
+      c2r_pair(ld_agent(xa + i), ld_agent(xa + N - i), w2i_g[i], oi, oj);
+      s_x[lds_pad(i)] = oi;
+      s_x[lds_pad(N - i)] = oj;
+    }
+  }
+  __syncthreads();
+  {
+    cpx v[E];
+    if (tid < T) {
+      pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+      pass_compute<LOGB, G::LOGE, 0, false>(v, tid, s_tab);
+    }
+    __syncthreads();
+    if (tid < T) pass_scatter<LOGB, G::LOGE, 0>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+    __syncthreads();
+    if (tid < T) {
+      pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+      pass_compute<LOGB, G::LOGE, 4, false>(v, tid, s_tab);
+    }
+    if constexpr (LOGB > 8) {
+      __syncthreads();
+      if (tid < T) pass_scatter<LOGB, G::LOGE, 4>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+      __syncthreads();
+      if (tid < T) {
+        pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+        pass_compute<LOGB, G::LOGE, 8, false>(v, tid, s_tab);
+      }
+    }
+    if (tid < T) {
+      constexpr float inv = 1.0f / (float)N;
+      cpx *o = reinterpret_cast<cpx *>(out + (long)ch * N);
+      cpx *tl = reinterpret_cast<cpx *>(tail + (long)ch * N);
+#pragma unroll
+      for (int e = 0; e < E / 2; e++) {
+        const int p = tid + T * e;
+        const cpx old = tl[p];
+        o[p] = mk((v[e].x + old.x) * inv, (v[e].y + old.y) * inv);
+        tl[p] = v[e + E / 2];
+      }
+    }
+  }
+}
+
+// log2 of the workgroups per channel of the cooperative block, or -1 when it does not apply: bins 512..4096, all
+// the workgroups resident at once is not required (nothing waits), but the slices should not get narrower than 32
+// bins (256-byte segments of a frame) and a workgroup's share of the two rings should stay a few hundred KiB —
+// longer filters need the whole chip on the partition axis (the split MAC + tree sum of the chain above)
+int pconv_coop_logs(const PconvGeom &g, const DeviceInfo &di) {
+  static const long cap_kb = [] {
+    const char *e = getenv("CLFA_PCONV_COOP_MAX_KB");   // tuning switch, read once; 0 switches the kernel off
+    return e ? atol(e) : 384L;
+  }();
+  if (g.logb < 9 || g.logb > 12 || cap_kb <= 0) return -1;
+  int logs = g.logb - 5;                                  // 32 bins per workgroup
+  const int logs_min = g.logb > 9 ? g.logb - 9 : 0;       // at most 256 16-byte items per workgroup (one per lane)
+  while (logs > logs_min && ((long)g.channels << logs) > di.num_cus) logs--;
+  if (((long)g.channels << logs) > 2L * di.num_cus) return -1;
+  const long share = 2L * g.nparts * (g.bins >> logs) * 8;   // bytes of the rings one workgroup streams
+  return share <= cap_kb * 1024 ? logs : -1;
+}
+
+template <int LOGB>
+static hipError_t launch_coop_one(const PconvGeom &g, int logs, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
+                                  float *tail, float *out, int frame1, int frame2, int wp, const cpx *half, const cpx *w2f,
+                                  const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s) {
+  const dim3 grid(1 << logs, g.channels);
+  if (in2)
+    hipLaunchKernelGGL((k_pconv_coop<LOGB, true>), grid, dim3(256), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
+                       wp, g.nparts, half, w2f, w2i, xacc, counters, logs);
+  else
+    hipLaunchKernelGGL((k_pconv_coop<LOGB, false>), grid, dim3(256), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
+                       wp, g.nparts, half, w2f, w2i, xacc, counters, logs);
+  return hipGetLastError();
+}
+
+hipError_t launch_pconv_coop(const PconvGeom &g, int logs, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
+                             float *tail, float *out, int frame1, int frame2, int wp, const cpx *half, const cpx *w2f,
+                             const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s) {
+  switch (g.logb) {
+#define CLFA_B(L) \
+  case L:         \
+    return launch_coop_one<L>(g, logs, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, xacc, counters, s);
+    CLFA_B(9) CLFA_B(10) CLFA_B(11) CLFA_B(12)
+#undef CLFA_B
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // partitions above the LDS sizes (pts = 16384, 32768): the same chain composed from the
 // large-N FFT kernel; these two kernels are its zero-padding and overlap-add ends
 // ---------------------------------------------------------------------------------

@@ -42,6 +42,57 @@ __device__ __forceinline__ void st_nt(cpx *p, cpx v) {
   __builtin_nontemporal_store(*reinterpret_cast<unsigned long long *>(&v), reinterpret_cast<unsigned long long *>(p));
 }
 
+// Transforms owned by a whole workgroup (T >= 256 lanes, one transform per workgroup): the transform's base is
+// wave-uniform, so its accesses go through a buffer descriptor — the lane's byte offset in ONE VGPR, everything
+// else (the element stride of the pass, the mirrored position of a pair's partner) in the instruction's scalar
+// offset.  With flat 64-bit addresses hipcc kept one address pair per access alive (16 pairs = 32 VGPRs for the
+// two store streams of the packed real kernels, under a 128-VGPR cap) and rebuilt them every iteration.
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+// (measured, interleaved A/B against flat addressing: r2c + c2r of size 16384 0.213 -> 0.203-0.208 ms; the complex
+// transforms, which have one ascending stream each way, lose 2 % at n = 8192 and stay as they were)
+template <int LOGN, int MODE> constexpr bool kLdsBufAddr = LdsGeom<LOGN>::FPW == 1 && LOGN >= 12 && MODE != MODE_C2C;
+struct XferBuf {
+  __amdgpu_buffer_rsrc_t r;
+  int va;   // t * 8: ascending positions t + c
+  int vd;   // (T - t) * 8: descending positions c - t, as vd + (c - T) * 8
+};
+template <int LOGN> __device__ __forceinline__ XferBuf xfer_buf(const cpx *x, int t) {
+  return XferBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<cpx *>(x), 0, 0x7fffffff, 0x00020000), t * 8,
+                 (LdsGeom<LOGN>::T - t) * 8};
+}
+__device__ __forceinline__ cpx ld_buf(const XferBuf &b, int voff, int soff) {
+  return __builtin_bit_cast(cpx, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 2));   // aux 2: non-temporal
+}
+__device__ __forceinline__ void st_buf(const XferBuf &b, int voff, int soff, cpx v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), b.r, voff, soff, 2);
+}
+// byte offsets (vector part, scalar part) of position i = pair_index(t, u, q) and of its partner N - i (N / 2 for
+// i = 0) of a paired remainder pass (fft_device.hpp); the u = 0 pairs carry lane 0's exceptions in the vector part
+template <int LOGN, int LOGE> struct PairOff {
+  int vi, si, vj, sj;
+};
+template <int LOGN, int LOGE> __device__ __forceinline__ PairOff<LOGN, LOGE> pair_off(const XferBuf &b, int t, int u, int q) {
+  constexpr int LOGR = pass_rem_logr(LOGN, LOGE), R = 1 << LOGR, T = 1 << (LOGN - LOGE), NB = 1 << (LOGN - LOGR), N = 1 << LOGN;
+  PairOff<LOGN, LOGE> o;
+  if (u == 0) {
+    const int i = pair_index<LOGN, LOGE>(t, 0, q);
+    o.vi = i * 8;
+    o.vj = (i == 0 ? N / 2 : N - i) * 8;
+    o.si = o.sj = 0;
+  } else if (q < R / 2) {   // i = t + u T + NB q ascending, partner N - i descending
+    o.vi = b.va;
+    o.si = (u * T + NB * q) * 8;
+    o.vj = b.vd;
+    o.sj = (N - NB * q - u * T - T) * 8;
+  } else {                  // i = NB (R - q) - (t + u T) descending, partner ascending
+    o.vi = b.vd;
+    o.si = (NB * (R - q) - u * T - T) * 8;
+    o.vj = b.va;
+    o.sj = (N - NB * (R - q) + u * T) * 8;
+  }
+  return o;
+}
+
 template <int LOGN, int MODE>
 __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const cpx *x, int t) {
   // No predicates on purpose: callers clamp the transform index instead.  Loads inside
@@ -50,6 +101,29 @@ __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const c
   // counted s_waitcnt vmcnt(N) and stay in flight behind the passes.
   using G = LdsGeom<LOGN>;
   constexpr int N = G::N, E = G::E, T = G::T;
+  if constexpr (kLdsBufAddr<LOGN, MODE>) {
+    const XferBuf b = xfer_buf<LOGN>(x, t);
+    if constexpr (MODE == MODE_C2R) {
+#pragma unroll
+      for (int k = 0; k < E / 2; k++) {
+        if constexpr (pair_ok(LOGN, G::LOGE)) {   // pairs in the order pass_first_paired wants them
+          constexpr int R = 1 << pass_rem_logr(LOGN, G::LOGE);
+          const auto o = pair_off<LOGN, G::LOGE>(b, t, k / R, k % R);
+          v[2 * k] = ld_buf(b, o.vi, o.si);
+          v[2 * k + 1] = ld_buf(b, o.vj, o.sj);
+        } else {
+          v[2 * k] = ld_buf(b, b.va, T * k * 8);
+          // partner N - (t + T k); pair 0 of lane 0 is (x[0], x[N/2])
+          if (k == 0) v[1] = ld_buf(b, t == 0 ? (N / 2) * 8 : (N - t) * 8, 0);
+          else v[2 * k + 1] = ld_buf(b, b.vd, (N - T * k - T) * 8);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; e++) v[e] = ld_buf(b, b.va, T * e * 8);
+    }
+    return;
+  }
   if constexpr (MODE == MODE_C2R) {
 #pragma unroll
     for (int k = 0; k < E / 2; k++) {
@@ -81,7 +155,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   __shared__ cpx s_x[FPW * G::PADN];
 
   const int tid = threadIdx.x;
-  const int f = tid / T, t = tid % T;
+  const int f = FPW == 1 ? 0 : tid / T, t = FPW == 1 ? tid : tid % T;   // (FPW == 1: the base stays provably uniform)
   const long groups = (batch + FPW - 1) / FPW;
   long g = blockIdx.x;
   if (g >= groups) return;   // whole workgroup (uniform): launchers never over-provision the grid
@@ -229,6 +303,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     // group whose transform index is past the batch were clamped to the LAST transform: they
     // loaded the same input in the same instruction as its owner and store bit-identical output.
     (void)active;
+    [[maybe_unused]] XferBuf xo{};
+    if constexpr (kLdsBufAddr<LOGN, MODE>) xo = xfer_buf<LOGN>(x, t);
     if constexpr (MODE == MODE_R2C && PAIRED) {
       // fused reference `conv` (cl_fft.cpp:178-191): both bins of every pair are in this lane's registers
       pairs_visit<LOGN, G::LOGE>(v, t, [&](int k, int i, cpx ci, cpx cj) {
@@ -239,8 +315,14 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
           oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
           oj = cj;
         }
-        st_nt(x + i, oi);
-        st_nt(x + j, oj);
+        if constexpr (kLdsBufAddr<LOGN, MODE>) {
+          const auto o = pair_off<LOGN, G::LOGE>(xo, t, k / RREM, k % RREM);
+          st_buf(xo, o.vi, o.si, oi);
+          st_buf(xo, o.vj, o.sj, oj);
+        } else {
+          st_nt(x + i, oi);
+          st_nt(x + j, oj);
+        }
       });
     } else if constexpr (MODE == MODE_R2C) {
       // fused reference `conv` (cl_fft.cpp:178-191) on the way out
@@ -260,9 +342,18 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
           oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
           oj = cj;
         }
-        st_nt(x + i, oi);
-        st_nt(x + j, oj);
+        if constexpr (kLdsBufAddr<LOGN, MODE>) {
+          st_buf(xo, xo.va, T * k * 8, oi);
+          if (k == 0) st_buf(xo, t == 0 ? (N / 2) * 8 : (N - t) * 8, 0, oj);
+          else st_buf(xo, xo.vd, (N - T * k - T) * 8, oj);
+        } else {
+          st_nt(x + i, oi);
+          st_nt(x + j, oj);
+        }
       }
+    } else if constexpr (kLdsBufAddr<LOGN, MODE>) {
+#pragma unroll
+      for (int e = 0; e < E; e++) st_buf(xo, xo.va, T * e * 8, v[e]);
     } else {
 #pragma unroll
       for (int e = 0; e < E; e++) st_nt(x + t + T * e, v[e]);

@@ -314,3 +314,56 @@ def test_pconv_push_ir_device_ragged_cvs():
     assert b.push_ir_device(d_ir[:, :1024]) == -30
     assert b.push_ir_device(d_ir[:2]) == -30
     assert b.push_ir_device(d_ir.double()) == -30
+
+
+@pytest.mark.parametrize("pts,nparts,channels,blocks,tv", [(512, 5, 1, 13, False), (512, 128, 1, 6, True), (512, 33, 4, 70, False),
+                                                          (1024, 8, 3, 20, True), (2048, 7, 2, 16, False),
+                                                          (4096, 3, 1, 8, True), (1024, 94, 2, 100, False),
+                                                          (4096, 2, 40, 5, False)])
+def test_pconv_cooperative_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
+    """few channels: one cooperative launch per block (k_pconv_coop: the bins of the multiply-accumulate split over
+    the workgroups of a channel, the last workgroup to arrive runs the inverse chain).  Static and time-varying,
+    partition counts that are not multiples of the partition rows, rings that wrap more than once, every block of
+    every channel against the oracle; twice the same input gives bit-identical output (fixed summation order)."""
+    s = util.lcg_half(31 + pts + nparts, channels * (pts * nparts + 2 * pts * blocks))
+    ir = s[:channels * pts * nparts].reshape(channels, pts * nparts)
+    x1 = s[channels * pts * nparts:channels * (pts * nparts + pts * blocks)].reshape(channels, pts * blocks)
+    x2 = s[channels * (pts * nparts + pts * blocks):].reshape(channels, pts * blocks)
+    outs = []
+    for rep in range(2):
+        p = fa.Clpconv(0, pts * nparts, pts, channels=channels)
+        assert p.get_cl_err() == 0 and p.kernel_name() == "k_pconv_coop"
+        if not tv:
+            assert p.push_ir(ir) == 0
+        outs.append(_run(p, blocks, pts, x1, x2 if tv else None))
+        assert (p.wp, p.wp2) == (blocks % nparts, (nparts - 1 - (blocks if tv else 0)) % nparts)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    for c in sorted({0, channels // 2, channels - 1}):
+        o = oracle.Pconv(pts * nparts, pts)
+        if not tv:
+            o.push_ir(ir[c])
+        want = np.concatenate([o.convolution(x1[c, b * pts:(b + 1) * pts], x2[c, b * pts:(b + 1) * pts] if tv else None)
+                               for b in range(blocks)])
+        assert_parity(outs[0][c], want, tol=CTOL, what="channel %d" % c)
+
+
+def test_pconv_cooperative_kernel_device_stream_of_blocks():
+    """the device-pointer path: 300 blocks queued back to back on one stream without any host synchronisation
+    (every launch finds its counters returned to zero by the launch before it), every block against the oracle"""
+    import torch
+    pts, nparts, blocks = 512, 128, 300
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ir = (torch.rand((1, pts * nparts), generator=g, device="cuda") - 0.5) / (pts * nparts) ** 0.5
+    x = torch.rand((blocks, 1, pts), generator=g, device="cuda") * 2 - 1
+    p = fa.Clpconv(0, pts * nparts, pts)
+    assert p.kernel_name() == "k_pconv_coop"
+    assert p.push_ir_device(ir) == 0
+    y = torch.empty((blocks, 1, pts), device="cuda")
+    for b in range(blocks):
+        assert p.process_device(y[b], x[b]) == 0
+    torch.cuda.synchronize()
+    o = oracle.Pconv(pts * nparts, pts)
+    o.push_ir(ir[0].cpu().numpy())
+    xs = x.cpu().numpy()
+    want = np.stack([o.convolution(xs[b, 0]) for b in range(blocks)])
+    assert_parity(y[:, 0].cpu().numpy(), want, tol=CTOL, what="300 blocks back to back")

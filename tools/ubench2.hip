@@ -401,6 +401,7 @@ template <int MODE> __global__ __launch_bounds__(512) void k_rev(f2 *data, long 
     for (int e = 0; e < 16; e++) {
       const bool desc = (MODE == 2 || MODE == 3) && (e & 1);
       v[e] = __builtin_nontemporal_load(x + (desc ? 511 - t : t) + 512 * e);
+      v[e].x += 1.0f;   // (an in-place copy of unchanged values is dead code)
     }
 #pragma unroll
     for (int e = 0; e < 16; e++) {
@@ -415,6 +416,37 @@ template <int MODE> __global__ __launch_bounds__(512) void k_rev(f2 *data, long 
       } else {
         __builtin_nontemporal_store(v[e], x + (desc ? 511 - t : t) + 512 * e);
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- rev2
+// LD / ST: lane order of the loads / stores of a 4 KiB row: 0 ascending, 1 descending on odd rows, 2 descending on
+// all rows, 3 wave order rotated by the row (wave w takes segment (w + e) % 8 of row e: a wave's 16 accesses no
+// longer fall 4 KiB apart); OOP: out of place; NT: non-temporal
+template <int LD, int ST, bool OOP, bool NT> __global__ __launch_bounds__(512) void k_rev2(f2 *dst, f2 *src, long chunks, float *sink) {
+  const int t = threadIdx.x;
+  auto pos = [&](int mode, int e) {
+    if (mode == 1) return (e & 1) ? 511 - t : t;
+    if (mode == 2) return 511 - t;
+    if (mode == 3) return (t + 64 * e) & 511;
+    return t;
+  };
+  for (long c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const f2 *x = src + c * 8192;
+    f2 *y = (OOP ? dst : src) + c * 8192;
+    f2 v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const f2 *p = x + pos(LD, e) + 512 * e;
+      v[e] = NT ? __builtin_nontemporal_load(p) : *p;
+      v[e].x += 1.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      f2 *p = y + pos(ST, e) + 512 * e;
+      if (NT) __builtin_nontemporal_store(v[e], p);
+      else *p = v[e];
     }
   }
 }
@@ -636,6 +668,28 @@ int main(int argc, char **argv) {
     for (int m = 0; m < 5; m++)
       printf("%-40s %6.2f %6.2f %6.2f\n", names[m], 2.0 * chunks * 65536 / t[m][0] * 1e-9, 2.0 * chunks * 65536 / t[m][1] * 1e-9,
              2.0 * chunks * 65536 / t[m][2] * 1e-9);
+  }
+
+  if (!strcmp(what, "rev2")) {
+    printf("\n[rev2] 512-lane workgroups, 2 per CU, 64 KiB chunks (32768 chunks = 2 GiB), 16 x 8-byte loads then 16 x 8-byte stores per lane;\n"
+           "       lane order per 4 KiB row: asc, alt (descending on odd rows), desc, rot (wave w takes segment (w + row) %% 8); TB/s (read + write)\n");
+    char *b2;
+    CK(hipMalloc(&b2, mats * 524288));
+    CK(hipMemset(b2, 0, mats * 524288));
+    const long chunks = 32768;
+    const char *on[] = {"asc", "alt", "desc", "rot"};
+#define R2(LD, ST, OOP, NT)                                                                                           \
+  {                                                                                                                   \
+    float best = 1e9f;                                                                                                \
+    for (int r = 0; r < 3; r++)                                                                                       \
+      best = std::min(best, time_launches(5, 30, [&] { hipLaunchKernelGGL((k_rev2<LD, ST, OOP, NT>), dim3(2 * cus), dim3(512), 0, 0, (f2 *)b2, (f2 *)a, chunks, sink); })); \
+    printf("loads %-4s stores %-4s %-12s %-5s  %6.2f\n", on[LD], on[ST], OOP ? "out of place" : "in place", NT ? "nt" : "plain", 2.0 * chunks * 65536 / best * 1e-9); \
+  }
+    R2(0, 0, false, true) R2(0, 0, true, true) R2(0, 0, false, false) R2(0, 0, true, false)
+    R2(0, 1, false, true) R2(0, 1, true, true) R2(1, 0, false, true) R2(1, 0, true, true) R2(1, 1, false, true) R2(1, 1, true, true)
+    R2(0, 2, false, true) R2(2, 0, false, true) R2(2, 2, false, true) R2(2, 2, true, true)
+    R2(3, 3, false, true) R2(3, 3, true, true) R2(0, 3, false, true) R2(3, 0, false, true)
+    CK(hipFree(b2));
   }
 
   if (all || !strcmp(what, "percu")) {
