@@ -289,7 +289,7 @@ struct clfa_pconv {
   DevBuf four, scratch, work;        // partitions above the LDS sizes: large-N tables, scratch, work frames
   StreamOrder order;
   bool fused = false;                // one launch per block (resolved at creation)
-  int coop_logs = -1;                // few channels: one cooperative launch per block, 2^coop_logs workgroups per channel
+  PconvCoop coop{-1, 1};             // few channels: one cooperative launch per block (logs >= 0)
   DevBuf cnt;                        // ... its arrival counters (one per channel)
   FftTables big;
 };
@@ -788,7 +788,7 @@ static int pconv_setup(clfa_pconv *p, int device, int cvs, int pts, int channels
   int e = device_info(device, p->di);
   if (e) return e;
   p->fused = pconv_fused_ok(p->g, p->di) && !getenv("CLFA_PCONV_NO_FUSE");   // tuning switch, read once
-  p->coop_logs = p->fused ? -1 : pconv_coop_logs(p->g, p->di);
+  if (!p->fused) p->coop = pconv_coop_plan(p->g, p->di);
   ENTER_DEVICE(device);
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   std::vector<cpx> h;
@@ -811,9 +811,10 @@ static int pconv_setup(clfa_pconv *p, int device, int cvs, int pts, int channels
   const size_t blk = sizeof(float) * (size_t)channels * pts;
   if ((e = p->ringA.ensure(ring))) return e;
   if ((e = p->ringB.ensure(ring))) return e;
-  if ((e = p->acc.ensure(sizeof(cpx) * (size_t)channels * pts * pconv_mac_split(p->g)))) return e;
+  const int acc_copies = p->coop.logs >= 0 ? p->coop.sparts : pconv_mac_split(p->g);
+  if ((e = p->acc.ensure(sizeof(cpx) * (size_t)channels * pts * acc_copies))) return e;
   if ((e = p->tail.ensure(blk))) return e;
-  if (p->coop_logs >= 0) {
+  if (p->coop.logs >= 0) {
     if ((e = p->cnt.ensure(sizeof(unsigned) * (size_t)channels))) return e;
     HIP_TRY(hipMemsetAsync(p->cnt.p, 0, sizeof(unsigned) * (size_t)channels, p->stream));
   }
@@ -857,7 +858,7 @@ int clfa_pconv_wp(const clfa_pconv *p) { return p ? p->wp : -1; }
 int clfa_pconv_wp2(const clfa_pconv *p) { return p ? p->wp2 : -1; }
 const char *clfa_pconv_kernel_name(const clfa_pconv *p) {
   if (!p || p->err) return "";
-  return p->fused ? "k_pconv_fused" : (p->coop_logs >= 0 ? "k_pconv_coop" : "chain");
+  return p->fused ? "k_pconv_fused" : (p->coop.logs >= 0 ? "k_pconv_coop" : "chain");
 }
 size_t clfa_pconv_state_bytes(const clfa_pconv *p) {
   return p ? p->ringA.bytes + p->ringB.bytes + p->acc.bytes + p->tail.bytes : 0;
@@ -934,13 +935,13 @@ int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(p->order.use(s));
   int e;
-  if (p->fused || p->coop_logs >= 0) {
+  if (p->fused || p->coop.logs >= 0) {
     // whole block in one launch; ring indices advance exactly as below
     const int frame1 = p->wp, frame2 = p->wp2;
     p->wp = p->wp != p->g.nparts - 1 ? p->wp + 1 : 0;
     if (in2) p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;
     if (!p->fused) {
-      HIP_TRY(launch_pconv_coop(p->g, p->coop_logs, (const float *)in1, (const float *)in2, (cpx *)p->ringA.p,
+      HIP_TRY(launch_pconv_coop(p->g, p->coop, (const float *)in1, (const float *)in2, (cpx *)p->ringA.p,
                                 (cpx *)p->ringB.p, (float *)p->tail.p, (float *)out, frame1, frame2, p->wp,
                                 (const cpx *)p->half.p, (const cpx *)p->w2f.p, (const cpx *)p->w2i.p, (cpx *)p->acc.p,
                                 (unsigned *)p->cnt.p, s));

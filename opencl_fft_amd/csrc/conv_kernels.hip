@@ -593,7 +593,8 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
                                                     float *__restrict__ tail, float *__restrict__ out, int frame1,
                                                     int frame2, int wp, int nparts, const cpx *__restrict__ tab_g,
                                                     const cpx *__restrict__ w2f_g, const cpx *__restrict__ w2i_g,
-                                                    cpx *__restrict__ xacc, unsigned *__restrict__ counters, int logs) {
+                                                    cpx *__restrict__ xacc, unsigned *__restrict__ counters, int logs,
+                                                    int sparts) {
   using G = LdsGeom<LOGB>;
   constexpr int N = G::N, E = G::E, T = G::T, HB = N / 2;   // N = bins; T = N/16 lanes run the FFTs
   static_assert(T <= 256 && N / 2 >= 256, "bins 512..4096");
@@ -604,7 +605,8 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
   __shared__ cpx2 s_red[256];
   __shared__ int s_last;
   const int tid = threadIdx.x;
-  const int ch = blockIdx.y, sl = blockIdx.x, S = 1 << logs;
+  // workgroup = (slice sl of the bins, segment ps of the partition axis)
+  const int ch = blockIdx.y, S = 1 << logs, sl = blockIdx.x & (S - 1), ps = blockIdx.x >> logs;
   for (int i = tid; i < N / 2; i += 256) s_tab[i] = tab_g[i];
   __syncthreads();
 
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
       }
       sf[i] = oi;
       sf[j] = oj;
-      if (sl == 0) {   // filed in the ring for the blocks to come; nobody reads it from there in this launch
+      if (blockIdx.x == 0) {   // filed in the ring for the blocks to come; nobody reads it from there in this launch
         x[i] = oi;
         x[j] = oj;
       }
@@ -684,9 +686,11 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
     // the frames written by THIS launch (frame1 of A; frame2 of B) are taken from LDS below: in the loop their
     // (stale) ring contents are read like any other frame and dropped by a select — no branch in the stream
     const int p1 = nparts - 1;                           // (wp + p1) % nparts == frame1: wp = frame1 + 1
+    const int chunk = (nparts + sparts - 1) / sparts;    // this workgroup's partitions [p_begin, p_end)
+    const int p_begin = ps * chunk, p_end = p_begin + chunk < nparts ? p_begin + chunk : nparts;
     constexpr int UNR = 4;
-    int p = pr;
-    for (; p + (UNR - 1) * nr < nparts; p += UNR * nr) {
+    int p = p_begin + pr;
+    for (; p + (UNR - 1) * nr < p_end; p += UNR * nr) {
       cpx2 av[UNR], bv[UNR];
       bool live[UNR];
 #pragma unroll
@@ -701,21 +705,21 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
 #pragma unroll
       for (int u = 0; u < UNR; u++) term(av[u], bv[u], live[u]);
     }
-    for (; p < nparts; p += nr) {
+    for (; p < p_end; p += nr) {
       int fr = wp + p;
       fr = fr < nparts ? fr : fr - nparts;
       term(ld_stream(a + (long)fr * HB), ld_stream(b + (long)p * HB), p != p1 && !(TV && p == frame2));
     }
     // the terms of the new frames, by the row that owns their partition
     const cpx2 *fa = reinterpret_cast<const cpx2 *>(s_fa) + item;
-    if (pr == p1 % nr) {
+    if (p1 >= p_begin && p1 < p_end && pr == (p1 - p_begin) % nr) {
       cpx2 bv;
       if (TV && p1 == frame2) bv = reinterpret_cast<const cpx2 *>(s_fb)[item];
       else bv = b[(long)p1 * HB];
       term(*fa, bv, true);
     }
     if constexpr (TV) {
-      if (frame2 != p1 && pr == frame2 % nr) {
+      if (frame2 != p1 && frame2 >= p_begin && frame2 < p_end && pr == (frame2 - p_begin) % nr) {
         int fr = wp + frame2;
         fr = fr < nparts ? fr : fr - nparts;
         term(a[(long)fr * HB], reinterpret_cast<const cpx2 *>(s_fb)[item], true);
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
         t0 = cadd(t0, s_red[r * iw + li].a);
         t1 = cadd(t1, s_red[r * iw + li].b);
       }
-      cpx *dst = xacc + (long)ch * N + 2 * item;
+      cpx *dst = xacc + ((long)ch * sparts + ps) * N + 2 * item;
       st_agent(dst, t0);
       st_agent(dst + 1, t1);
     }
@@ -742,22 +746,27 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
   __syncthreads();
   if (tid == 0) {
     const unsigned old = __hip_atomic_fetch_add(counters + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = old == (unsigned)(S - 1);
+    s_last = old == (unsigned)(S * sparts - 1);
     if (s_last) __hip_atomic_store(counters + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch
   }
   __syncthreads();
   if (!s_last) return;
 
   // ---- inverse chain: c2r + inverse FFT + overlap-add (cl_conv_kernels.h:87-100, 120-124) -------------
-  const cpx *xa = xacc + (long)ch * N;
+  const cpx *xa = xacc + (long)ch * sparts * N;
+  auto xsum = [&](int i) {   // the segments' partial sums in ascending order
+    cpx sum = ld_agent(xa + i);
+    for (int k = 1; k < sparts; k++) sum = cadd(sum, ld_agent(xa + (long)k * N + i));
+    return sum;
+  };
   for (int i = tid; i < N / 2; i += 256) {
     if (i == 0) {
-      const cpx c0 = ld_agent(xa);
+      const cpx c0 = xsum(0);
       s_x[0] = mk(c0.x + c0.y, c0.x - c0.y);
-      s_x[lds_pad(N / 2)] = ld_agent(xa + N / 2);
+      s_x[lds_pad(N / 2)] = xsum(N / 2);
     } else {
       cpx oi, oj;
-      c2r_pair(ld_agent(xa + i), ld_agent(xa + N - i), w2i_g[i], oi, oj);
+      c2r_pair(xsum(i), xsum(N - i), w2i_g[i], oi, oj);
       s_x[lds_pad(i)] = oi;
       s_x[lds_pad(N - i)] = oj;
     }
@@ -800,45 +809,55 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
   }
 }
 
-// log2 of the workgroups per channel of the cooperative block, or -1 when it does not apply: bins 512..4096, all
-// the workgroups resident at once is not required (nothing waits), but the slices should not get narrower than 32
-// bins (256-byte segments of a frame) and a workgroup's share of the two rings should stay a few hundred KiB —
-// longer filters need the whole chip on the partition axis (the split MAC + tree sum of the chain above)
-int pconv_coop_logs(const PconvGeom &g, const DeviceInfo &di) {
+// Shape of the cooperative block, or logs = -1 when it does not apply: bins 512..4096; slices of 32 bins (256-byte
+// segments of a frame) unless the channels alone would overfill the chip; the partition axis cut into segments until
+// a workgroup's share of the two rings is at most CLFA_PCONV_COOP_MAX_KB (tuning switch, read once; 0 switches the
+// kernel off), as far as one workgroup per CU goes; shares beyond 4 x that stay with the launch chain above (the
+// split MAC + tree sum), which puts the whole chip on the partition axis.
+PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di) {
   static const long cap_kb = [] {
-    const char *e = getenv("CLFA_PCONV_COOP_MAX_KB");   // tuning switch, read once; 0 switches the kernel off
-    return e ? atol(e) : 384L;
+    const char *e = getenv("CLFA_PCONV_COOP_MAX_KB");
+    return e ? atol(e) : 128L;
   }();
-  if (g.logb < 9 || g.logb > 12 || cap_kb <= 0) return -1;
+  PconvCoop c{-1, 1};
+  if (g.logb < 9 || g.logb > 12 || cap_kb <= 0) return c;
   int logs = g.logb - 5;                                  // 32 bins per workgroup
   const int logs_min = g.logb > 9 ? g.logb - 9 : 0;       // at most 256 16-byte items per workgroup (one per lane)
   while (logs > logs_min && ((long)g.channels << logs) > di.num_cus) logs--;
-  if (((long)g.channels << logs) > 2L * di.num_cus) return -1;
-  const long share = 2L * g.nparts * (g.bins >> logs) * 8;   // bytes of the rings one workgroup streams
-  return share <= cap_kb * 1024 ? logs : -1;
+  if (((long)g.channels << logs) > 2L * di.num_cus) return c;
+  const long share = 2L * g.nparts * (g.bins >> logs) * 8;   // bytes of the rings one bin slice streams
+  long sparts = (share + cap_kb * 1024 - 1) / (cap_kb * 1024);
+  const long room = di.num_cus / ((long)g.channels << logs);
+  if (sparts > room) sparts = room;
+  if (sparts > g.nparts / 4) sparts = g.nparts / 4;          // segments of at least 4 partitions
+  if (sparts < 1) sparts = 1;
+  if (share / sparts > 4 * cap_kb * 1024) return c;
+  c.logs = logs;
+  c.sparts = (int)sparts;
+  return c;
 }
 
 template <int LOGB>
-static hipError_t launch_coop_one(const PconvGeom &g, int logs, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
+static hipError_t launch_coop_one(const PconvGeom &g, PconvCoop c, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                                   float *tail, float *out, int frame1, int frame2, int wp, const cpx *half, const cpx *w2f,
                                   const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s) {
-  const dim3 grid(1 << logs, g.channels);
+  const dim3 grid(c.sparts << c.logs, g.channels);
   if (in2)
     hipLaunchKernelGGL((k_pconv_coop<LOGB, true>), grid, dim3(256), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
-                       wp, g.nparts, half, w2f, w2i, xacc, counters, logs);
+                       wp, g.nparts, half, w2f, w2i, xacc, counters, c.logs, c.sparts);
   else
     hipLaunchKernelGGL((k_pconv_coop<LOGB, false>), grid, dim3(256), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
-                       wp, g.nparts, half, w2f, w2i, xacc, counters, logs);
+                       wp, g.nparts, half, w2f, w2i, xacc, counters, c.logs, c.sparts);
   return hipGetLastError();
 }
 
-hipError_t launch_pconv_coop(const PconvGeom &g, int logs, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
+hipError_t launch_pconv_coop(const PconvGeom &g, PconvCoop c, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                              float *tail, float *out, int frame1, int frame2, int wp, const cpx *half, const cpx *w2f,
                              const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s) {
   switch (g.logb) {
 #define CLFA_B(L) \
   case L:         \
-    return launch_coop_one<L>(g, logs, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, xacc, counters, s);
+    return launch_coop_one<L>(g, c, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, xacc, counters, s);
     CLFA_B(9) CLFA_B(10) CLFA_B(11) CLFA_B(12)
 #undef CLFA_B
     default:

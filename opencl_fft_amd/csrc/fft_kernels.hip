@@ -34,12 +34,21 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //               pair 0 of lane 0 is (x[0], x[N/2])
 // every transform is read once and written once: non-temporal streams (copy kernels on this chip:
 // 5.2 TB/s with nt vs 4.95 plain)
+// (CLFA_NT_LD / CLFA_NT_ST: tuning switches for A/B builds; the library's choice is the default)
+#ifndef CLFA_NT_LD
+#define CLFA_NT_LD 1
+#endif
+#ifndef CLFA_NT_ST
+#define CLFA_NT_ST 1
+#endif
 __device__ __forceinline__ cpx ld_nt(const cpx *p) {
-  const unsigned long long raw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
+  const unsigned long long raw = CLFA_NT_LD ? __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p))
+                                            : *reinterpret_cast<const unsigned long long *>(p);
   return *reinterpret_cast<const cpx *>(&raw);
 }
 __device__ __forceinline__ void st_nt(cpx *p, cpx v) {
-  __builtin_nontemporal_store(*reinterpret_cast<unsigned long long *>(&v), reinterpret_cast<unsigned long long *>(p));
+  if (CLFA_NT_ST) __builtin_nontemporal_store(*reinterpret_cast<unsigned long long *>(&v), reinterpret_cast<unsigned long long *>(p));
+  else *reinterpret_cast<unsigned long long *>(p) = *reinterpret_cast<unsigned long long *>(&v);
 }
 
 // Transforms owned by a whole workgroup (T >= 256 lanes, one transform per workgroup): the transform's base is
@@ -60,11 +69,21 @@ template <int LOGN> __device__ __forceinline__ XferBuf xfer_buf(const cpx *x, in
   return XferBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<cpx *>(x), 0, 0x7fffffff, 0x00020000), t * 8,
                  (LdsGeom<LOGN>::T - t) * 8};
 }
-__device__ __forceinline__ cpx ld_buf(const XferBuf &b, int voff, int soff) {
-  return __builtin_bit_cast(cpx, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 2));   // aux 2: non-temporal
+// Cache policy of the packed real kernels' loads: PLAIN loads, non-temporal stores.  Measured (interleaved A/B, steps
+// alternating r2c / c2r, 1 GiB): size 16384 0.2054 -> 0.1974 ms (5.23 -> 5.44 TB/s) with both directions' loads plain,
+// 0.2012 / 0.2027 with one of them; sizes 8192 and 32768 within 1 %.  (The complex kernels lose 2-9 % with plain
+// loads and 3-8 % with plain stores: they keep non-temporal both ways — profiles/ab_cache_policy_r03.txt.)
+#ifndef CLFA_NT_LD_R2C
+#define CLFA_NT_LD_R2C 0
+#endif
+#ifndef CLFA_NT_LD_C2R
+#define CLFA_NT_LD_C2R 0
+#endif
+template <bool NT> __device__ __forceinline__ cpx ld_buf(const XferBuf &b, int voff, int soff) {
+  return __builtin_bit_cast(cpx, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, NT ? 2 : 0));   // aux 2: non-temporal
 }
 __device__ __forceinline__ void st_buf(const XferBuf &b, int voff, int soff, cpx v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), b.r, voff, soff, 2);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), b.r, voff, soff, CLFA_NT_ST ? 2 : 0);
 }
 // byte offsets (vector part, scalar part) of position i = pair_index(t, u, q) and of its partner N - i (N / 2 for
 // i = 0) of a paired remainder pass (fft_device.hpp); the u = 0 pairs carry lane 0's exceptions in the vector part
@@ -103,24 +122,25 @@ __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const c
   constexpr int N = G::N, E = G::E, T = G::T;
   if constexpr (kLdsBufAddr<LOGN, MODE>) {
     const XferBuf b = xfer_buf<LOGN>(x, t);
+    constexpr bool NT = MODE == MODE_C2R ? CLFA_NT_LD_C2R : CLFA_NT_LD_R2C;
     if constexpr (MODE == MODE_C2R) {
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {
         if constexpr (pair_ok(LOGN, G::LOGE)) {   // pairs in the order pass_first_paired wants them
           constexpr int R = 1 << pass_rem_logr(LOGN, G::LOGE);
           const auto o = pair_off<LOGN, G::LOGE>(b, t, k / R, k % R);
-          v[2 * k] = ld_buf(b, o.vi, o.si);
-          v[2 * k + 1] = ld_buf(b, o.vj, o.sj);
+          v[2 * k] = ld_buf<NT>(b, o.vi, o.si);
+          v[2 * k + 1] = ld_buf<NT>(b, o.vj, o.sj);
         } else {
-          v[2 * k] = ld_buf(b, b.va, T * k * 8);
+          v[2 * k] = ld_buf<NT>(b, b.va, T * k * 8);
           // partner N - (t + T k); pair 0 of lane 0 is (x[0], x[N/2])
-          if (k == 0) v[1] = ld_buf(b, t == 0 ? (N / 2) * 8 : (N - t) * 8, 0);
-          else v[2 * k + 1] = ld_buf(b, b.vd, (N - T * k - T) * 8);
+          if (k == 0) v[1] = ld_buf<NT>(b, t == 0 ? (N / 2) * 8 : (N - t) * 8, 0);
+          else v[2 * k + 1] = ld_buf<NT>(b, b.vd, (N - T * k - T) * 8);
         }
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < E; e++) v[e] = ld_buf(b, b.va, T * e * 8);
+      for (int e = 0; e < E; e++) v[e] = ld_buf<NT>(b, b.va, T * e * 8);
     }
     return;
   }

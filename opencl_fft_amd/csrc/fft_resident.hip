@@ -55,6 +55,23 @@
 namespace clfa {
 namespace {
 
+// cache policy of the streams (tuning switches for A/B builds; the library's choice is the default)
+#ifndef CLFA_NT_LD
+#define CLFA_NT_LD 1
+#endif
+#ifndef CLFA_NT_ST
+#define CLFA_NT_ST 1
+#endif
+#if CLFA_NT_LD
+#define CLFA_LDNT " nt"
+#else
+#define CLFA_LDNT ""
+#endif
+#if CLFA_NT_ST
+#define CLFA_STNT " nt"
+#else
+#define CLFA_STNT ""
+#endif
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f32x32 __attribute__((ext_vector_type(32)));
@@ -138,7 +155,7 @@ template <int PROBE = 0> __device__ __forceinline__ void res_store(const cpx (&v
       cpx t = v[e];
       asm volatile("" : "+v"(t));
     } else {
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v[e]), r, voff, e * 32768, 2);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v[e]), r, voff, e * 32768, CLFA_NT_ST ? 2 : 0);
     }
   }
 }
@@ -154,14 +171,14 @@ template <int PROBE = 0> __device__ __forceinline__ void res_store(const cpx (&v
 template <int COL, int E0> __device__ __forceinline__ void res_load_acc8(__amdgpu_buffer_rsrc_t r, int voff) {
 #define CLFA_LD "buffer_load_dwordx2 a[%c"
   asm volatile("s_nop 4\n\t"
-               "buffer_load_dwordx2 a[%c2:%c3], %0, %1, %18 offen nt\n\t"
-               "buffer_load_dwordx2 a[%c4:%c5], %0, %1, %19 offen nt\n\t"
-               "buffer_load_dwordx2 a[%c6:%c7], %0, %1, %20 offen nt\n\t"
-               "buffer_load_dwordx2 a[%c8:%c9], %0, %1, %21 offen nt\n\t"
-               "buffer_load_dwordx2 a[%c10:%c11], %0, %1, %22 offen nt\n\t"
-               "buffer_load_dwordx2 a[%c12:%c13], %0, %1, %23 offen nt\n\t"
-               "buffer_load_dwordx2 a[%c14:%c15], %0, %1, %24 offen nt\n\t"
-               "buffer_load_dwordx2 a[%c16:%c17], %0, %1, %25 offen nt"
+               "buffer_load_dwordx2 a[%c2:%c3], %0, %1, %18 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 a[%c4:%c5], %0, %1, %19 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 a[%c6:%c7], %0, %1, %20 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 a[%c8:%c9], %0, %1, %21 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 a[%c10:%c11], %0, %1, %22 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 a[%c12:%c13], %0, %1, %23 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 a[%c14:%c15], %0, %1, %24 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 a[%c16:%c17], %0, %1, %25 offen" CLFA_LDNT
                :
                : "v"(voff), "s"(r), "n"(0 * 32 + 2 * COL), "n"(0 * 32 + 2 * COL + 1), "n"(1 * 32 + 2 * COL),
                  "n"(1 * 32 + 2 * COL + 1), "n"(2 * 32 + 2 * COL), "n"(2 * 32 + 2 * COL + 1), "n"(3 * 32 + 2 * COL),
@@ -189,14 +206,14 @@ template <int CB, int... E> __device__ __forceinline__ void acc_fetch_raw(cpx (&
 // (with compiler-allocated destinations it did: it moved them ahead of the wait).
 template <int E0> __device__ __forceinline__ void res_load_land8(__amdgpu_buffer_rsrc_t r, int voff) {
   asm volatile("s_nop 4\n\t"
-               "buffer_load_dwordx2 v[%c2:%c3], %0, %1, %18 offen nt\n\t"
-               "buffer_load_dwordx2 v[%c4:%c5], %0, %1, %19 offen nt\n\t"
-               "buffer_load_dwordx2 v[%c6:%c7], %0, %1, %20 offen nt\n\t"
-               "buffer_load_dwordx2 v[%c8:%c9], %0, %1, %21 offen nt\n\t"
-               "buffer_load_dwordx2 v[%c10:%c11], %0, %1, %22 offen nt\n\t"
-               "buffer_load_dwordx2 v[%c12:%c13], %0, %1, %23 offen nt\n\t"
-               "buffer_load_dwordx2 v[%c14:%c15], %0, %1, %24 offen nt\n\t"
-               "buffer_load_dwordx2 v[%c16:%c17], %0, %1, %25 offen nt"
+               "buffer_load_dwordx2 v[%c2:%c3], %0, %1, %18 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 v[%c4:%c5], %0, %1, %19 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 v[%c6:%c7], %0, %1, %20 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 v[%c8:%c9], %0, %1, %21 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 v[%c10:%c11], %0, %1, %22 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 v[%c12:%c13], %0, %1, %23 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 v[%c14:%c15], %0, %1, %24 offen" CLFA_LDNT "\n\t"
+               "buffer_load_dwordx2 v[%c16:%c17], %0, %1, %25 offen" CLFA_LDNT
                :
                : "v"(voff), "s"(r), "n"(224 + 2 * E0), "n"(225 + 2 * E0), "n"(226 + 2 * E0), "n"(227 + 2 * E0),
                  "n"(228 + 2 * E0), "n"(229 + 2 * E0), "n"(230 + 2 * E0), "n"(231 + 2 * E0), "n"(232 + 2 * E0),
@@ -248,9 +265,9 @@ template <int CB> struct HookAcc {   // -> AGPR columns CB, CB + 1 (a landing zo
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
     constexpr int lo = 32 * (K & 7) + 2 * (K < 8 ? CB : CB + 1);
     if constexpr (K == 0)   // the descriptor's SGPRs may be fresh from SALU: 5 wait states before VMEM reads them
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
     else
-      asm volatile("buffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
+      asm volatile("buffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
   }
 };
 struct HookLand {   // -> landing registers v[224:255]
@@ -259,9 +276,9 @@ struct HookLand {   // -> landing registers v[224:255]
   const int (&so)[16];
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
     if constexpr (K == 0)
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
     else
-      asm volatile("buffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+      asm volatile("buffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
   }
 };
 // block 15 of phase 1 has nothing left to prefetch: its hooks bring the global slot's row block back
@@ -289,9 +306,9 @@ struct HookStore {
   const int (&so)[16];
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
     if constexpr (K == 0)
-      asm volatile("s_nop 4\n\tbuffer_store_dwordx2 v[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_store_dwordx2 v[%c2:%c3], %0, %1, %4 offen" CLFA_STNT ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
     else
-      asm volatile("buffer_store_dwordx2 v[%c2:%c3], %0, %1, %4 offen nt" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+      asm volatile("buffer_store_dwordx2 v[%c2:%c3], %0, %1, %4 offen" CLFA_STNT ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
   }
 };
 __device__ __forceinline__ void res_stage(const cpx (&v)[16]) {

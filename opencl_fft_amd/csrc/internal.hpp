@@ -109,11 +109,15 @@ hipError_t launch_pconv_mac(const PconvGeom &g, const cpx *ringA, const cpx *rin
 hipError_t launch_pconv_inverse(const PconvGeom &g, const cpx *acc, float *tail, float *out,
                                 const cpx *half, const cpx *w2i, hipStream_t s, int nsplit = 1);
 // one launch per block (forward + MAC + inverse in one workgroup per channel); used when
-// one launch per block for a FEW channels (conv_kernels.hip, k_pconv_coop): log2 of the workgroups per channel, or
-// -1 when the kernel does not apply; xacc: channels x bins complex (hand-over of the accumulator slices),
-// counters: one zero-initialised unsigned per channel (returned to zero by every launch)
-int pconv_coop_logs(const PconvGeom &g, const DeviceInfo &di);
-hipError_t launch_pconv_coop(const PconvGeom &g, int logs, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
+// one launch per block for a FEW channels (conv_kernels.hip, k_pconv_coop): 2^logs bin slices x sparts segments of
+// the partition axis per channel (logs = -1: the kernel does not apply); xacc: channels x sparts x bins complex
+// (hand-over of the accumulator slices), counters: one zero-initialised unsigned per channel (returned to zero by
+// every launch)
+struct PconvCoop {
+  int logs, sparts;
+};
+PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di);
+hipError_t launch_pconv_coop(const PconvGeom &g, PconvCoop c, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                              float *tail, float *out, int frame1, int frame2, int wp, const cpx *half, const cpx *w2f,
                              const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s);
 // pconv_fused_ok(): bins 512..4096 and enough channels to fill the chip

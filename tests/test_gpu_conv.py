@@ -319,7 +319,10 @@ def test_pconv_push_ir_device_ragged_cvs():
 @pytest.mark.parametrize("pts,nparts,channels,blocks,tv", [(512, 5, 1, 13, False), (512, 128, 1, 6, True), (512, 33, 4, 70, False),
                                                           (1024, 8, 3, 20, True), (2048, 7, 2, 16, False),
                                                           (4096, 3, 1, 8, True), (1024, 94, 2, 100, False),
-                                                          (4096, 2, 40, 5, False)])
+                                                          (4096, 2, 40, 5, False),
+                                                          # long filters: the partition axis cut into segments as well
+                                                          (512, 600, 1, 8, True), (1024, 1000, 2, 6, False),
+                                                          (512, 2048, 1, 5, False)])
 def test_pconv_cooperative_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
     """few channels: one cooperative launch per block (k_pconv_coop: the bins of the multiply-accumulate split over
     the workgroups of a channel, the last workgroup to arrive runs the inverse chain).  Static and time-varying,

@@ -1,7 +1,7 @@
 """dev tool: interleaved A/B of two builds of libclfft_amd.so in ONE process, on realistic data
 (steps alternate forward / inverse plans so the values stay O(1): all-zero or inf data draw less
 power and run at higher clocks, which flatters repeated same-direction loops).
-usage: python tools/ab_libs.py <old.so> [rfft|c2c|c2c8192]"""
+usage: python tools/ab_libs.py <old.so> [rfft|rfft<size>|c2c|c2c<n>] [swap]"""
 import ctypes as C, statistics, sys
 sys.path.insert(0, ".")
 import torch
@@ -12,22 +12,24 @@ old = C.CDLL(sys.argv[1])
 for name, res, args in L.SYMBOLS:
     f = getattr(old, name); f.restype = res; f.argtypes = args
 what = sys.argv[2] if len(sys.argv) > 2 else "rfft"
+rsize = int(what[4:]) if what.startswith("rfft") and len(what) > 4 else 16384   # rfft<size>: another packed real size
 
 def plans(lib):
     out = []
     for fwd in (1, 0):
         h = C.c_void_p()
-        if what == "rfft":
-            e = lib.clfa_rfft_create(C.byref(h), 0, 16384, fwd)
+        if what.startswith("rfft"):
+            e = lib.clfa_rfft_create(C.byref(h), 0, rsize, fwd)
         else:
             e = lib.clfa_cfft_create(C.byref(h), 0, int(what[3:]) if len(what) > 3 else 65536, fwd)
         assert e == 0
         out.append(h)
     return out
 
-if what == "rfft":
-    batch, d = 8192, torch.rand((8192, 16384), device="cuda") * 2 - 1
-    unit = 8192 * 16384 * 8
+if what.startswith("rfft"):
+    batch = (1 << 27) // rsize
+    d = torch.rand((batch, rsize), device="cuda") * 2 - 1
+    unit = batch * rsize * 8
 elif len(what) > 3:
     n = int(what[3:])
     batch = (1 << 28) // n

@@ -48,11 +48,19 @@ template <bool W16> struct Blk {
 struct Geo {
   int voff8, voff16;
 };
-__device__ __forceinline__ Geo geo() {
+// MAP (8-byte accesses only): which (column c, row residue t) a lane takes — any bijection is free in the real kernel
+// (the LDS exchanges re-label the lanes): 0 c = l & 15, t = l >> 4; 1 c reversed; 2 rows interleaved over the waves
+// (wave w takes t = w, w + 4, w + 8, w + 12); 3 both; 4 t reversed; 5 c and t reversed; 6 c reversed on odd t
+template <int MAP = 0> __device__ __forceinline__ Geo geo() {
   int l = threadIdx.x;
   asm volatile("" : "+v"(l));
   Geo g;
-  g.voff8 = (l >> 4) * 2048 + (l & 15) * 8;
+  int c = l & 15, t = l >> 4;
+  if (MAP == 1 || MAP == 3 || MAP == 5) c = 15 - c;
+  if (MAP == 2 || MAP == 3) t = (l >> 6) + 4 * ((l >> 4) & 3);
+  if (MAP == 4 || MAP == 5) t = 15 - t;
+  if (MAP == 6) c = (t & 1) ? 15 - c : c;
+  g.voff8 = t * 2048 + c * 8;
   const int lam = l & 63, w = l >> 6, j = lam & 7, tl = (lam >> 3) & 3, up = lam >> 5;
   g.voff16 = (4 * w + tl + 16 * up) * 2048 + j * 16;
   return g;
@@ -137,7 +145,8 @@ __device__ __forceinline__ void p1_block(Blk<LW16> &z, Acc &A, const char *x, in
 }
 template <int W, bool SW16, bool XCHG, bool NOMEM, bool PRE, bool LW16, int... K>
 __device__ __forceinline__ void p2_block(Acc &A, char *x, int cb, const Geo &g, f2 *sx, f2 (&st)[16],
-                                         std::integer_sequence<int, K...>, Blk<LW16> *zn = nullptr, const char *xn = nullptr) {
+                                         std::integer_sequence<int, K...>, Blk<LW16> *zn = nullptr, const char *xn = nullptr,
+                                         const Geo *gl = nullptr) {
   // st = the previous block's results (parked); this block's arithmetic carries their stores
   const __amdgpu_buffer_rsrc_t r = rsrc(x + cb * 128);
   f2 cur[16];
@@ -154,8 +163,8 @@ __device__ __forceinline__ void p2_block(Acc &A, char *x, int cb, const Geo &g, 
     }
     if constexpr (PRE) {
       const __amdgpu_buffer_rsrc_t rn = rsrc(xn);
-      if constexpr (!LW16) load_one<false, kk>(*zn, rn, g);
-      else if constexpr (kk % 2 == 1) load_one<true, kk / 2>(*zn, rn, g);
+      if constexpr (!LW16) load_one<false, kk>(*zn, rn, *gl);
+      else if constexpr (kk % 2 == 1) load_one<true, kk / 2>(*zn, rn, *gl);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -172,7 +181,7 @@ __device__ __forceinline__ void p2_block(Acc &A, char *x, int cb, const Geo &g, 
 }
 
 // MODE bits: 1 no loads, 2 no stores (what each stream costs)
-template <int DEPTH, int W, bool LW16, bool SW16, bool XCHG, int MODE = 0>
+template <int DEPTH, int W, bool LW16, bool SW16, bool XCHG, int MODE = 0, int MAPL = 0, int MAPS = 0>
 __global__ __launch_bounds__(256) void k_model2(char *data, long mats, unsigned long long *dbg, float *sink) {
   __shared__ f2 sx[16 * 258 + 64];
   Acc A;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256) void k_model2(char *data, long mats, unsigned 
   if (m >= mats) return;
   // prologue: the first DEPTH blocks of the first transform
   {
-    const Geo g = geo();
+    const Geo g = geo<MAPL>();
     const char *x = data + m * 524288;
     auto pro = [&](auto zc) {
       constexpr int Z = decltype(zc)::value;
@@ -213,14 +222,14 @@ __global__ __launch_bounds__(256) void k_model2(char *data, long mats, unsigned 
     constexpr int ROUNDS = (16 - DEPTH) / DEPTH;   // rounds of DEPTH blocks that still prefetch
 #pragma unroll 1
     for (int rd = 0; rd < ROUNDS; rd++) {
-      const Geo g = geo();
+      const Geo g = geo<MAPL>();
       [&]<int... Z>(std::integer_sequence<int, Z...>) {
         (p1_block<W, LW16, XCHG, true, NOLD>(z[Z], A, x, rd * DEPTH + Z + DEPTH, g, sx, S16()), ...);
       }(std::make_integer_sequence<int, DEPTH>());
     }
     // tail: the remaining blocks (ROUNDS * DEPTH .. 15), prefetching while a block DEPTH ahead exists
     {
-      const Geo g = geo();
+      const Geo g = geo<MAPL>();
       [&]<int... I>(std::integer_sequence<int, I...>) {
         auto tail = [&](auto i) {
           constexpr int cb = ROUNDS * DEPTH + decltype(i)::value;
@@ -239,19 +248,19 @@ __global__ __launch_bounds__(256) void k_model2(char *data, long mats, unsigned 
 #pragma unroll
     for (int e = 0; e < 16; e++) st[e] = A.a[e & 7];
     {
-      const Geo g = geo();
+      const Geo g = geo<MAPS>();
       p2_block<W, SW16, XCHG, true, false, LW16>(A, x, 0, g, sx, st, S16());
     }
 #pragma unroll 1
     for (int cb = 1; cb < 16 - DEPTH; cb++) {
-      const Geo g = geo();
+      const Geo g = geo<MAPS>();
       p2_block<W, SW16, XCHG, NOST, false, LW16>(A, x, cb - 1, g, sx, st, S16());
     }
     {
       // the last DEPTH row blocks also carry the loads of the next transform's first DEPTH column blocks
-      const Geo g = geo();
+      const Geo g = geo<MAPS>(), gl = geo<MAPL>();
       [&]<int... Z>(std::integer_sequence<int, Z...>) {
-        (p2_block<W, SW16, XCHG, NOST, !NOLD, LW16>(A, x, 16 - DEPTH + Z - 1, g, sx, st, S16(), &z[Z], xn + Z * 128), ...);
+        (p2_block<W, SW16, XCHG, NOST, !NOLD, LW16>(A, x, 16 - DEPTH + Z - 1, g, sx, st, S16(), &z[Z], xn + Z * 128, &gl), ...);
       }(std::make_integer_sequence<int, DEPTH>());
       const __amdgpu_buffer_rsrc_t r = rsrc(x + 15 * 128);
       if constexpr (!NOST) [&]<int... K>(std::integer_sequence<int, K...>) { (store_one<SW16, K>(st, r, g), ...); }(S16());
@@ -690,6 +699,46 @@ int main(int argc, char **argv) {
     R2(0, 2, false, true) R2(2, 0, false, true) R2(2, 2, false, true) R2(2, 2, true, true)
     R2(3, 3, false, true) R2(3, 3, true, true) R2(0, 3, false, true) R2(3, 0, false, true)
     CK(hipFree(b2));
+  }
+
+  if (!strcmp(what, "maps")) {
+    printf("\n[maps] model2 (depth 2, W 22, 8-byte accesses, exchange on) with other lane -> (column, row) maps for the loads / stores:\n"
+           "       0 as the kernel; 1 columns reversed; 2 rows interleaved over the waves; 3 = 1 + 2; 4 rows reversed; 5 = 1 + 4; 6 columns reversed on odd rows\n");
+    struct Shape {
+      char name[96];
+      std::function<void()> launch;
+      std::vector<float> ms;
+      double p1, p2;
+    };
+    std::vector<Shape> shapes;
+#define MP(ML, MS)                                                                                                        \
+  {                                                                                                                       \
+    Shape s;                                                                                                              \
+    snprintf(s.name, sizeof s.name, "load map %d  store map %d", ML, MS);                                                 \
+    s.launch = [=] { hipLaunchKernelGGL((k_model2<2, 22, false, false, true, 0, ML, MS>), dim3(cus), dim3(256), 0, 0, a, mats, dbg, sink); }; \
+    shapes.push_back(s);                                                                                                  \
+  }
+    MP(0, 0) MP(0, 1) MP(1, 0) MP(1, 1) MP(0, 2) MP(2, 0) MP(2, 2) MP(0, 3) MP(3, 3) MP(0, 4) MP(4, 0) MP(0, 5) MP(5, 5) MP(0, 6) MP(6, 0) MP(6, 6)
+    MP(1, 2) MP(2, 1) MP(4, 4)
+    for (int round = 0; round < 4; round++)
+      for (auto &sh : shapes) {
+        sh.ms.push_back(time_launches(6, 30, sh.launch));
+        CK(hipMemcpy(hdbg.data(), dbg, 2 * cus * 8, hipMemcpyDeviceToHost));
+        double s1 = 0, s2 = 0;
+        for (int i = 0; i < cus; i++) {
+          s1 += hdbg[2 * i];
+          s2 += hdbg[2 * i + 1];
+        }
+        sh.p1 = s1 / mats * 1e-3;
+        sh.p2 = s2 / mats * 1e-3;
+      }
+    const double by = 2.0 * (double)mats * 524288;
+    for (auto &sh : shapes) {
+      std::vector<float> v = sh.ms;
+      std::sort(v.begin(), v.end());
+      printf("%-30s %7.3f ms (min %.3f)  %5.2f TB/s   p1 %5.1f  p2 %5.1f\n", sh.name, v[v.size() / 2], v.front(),
+             by / v[v.size() / 2] * 1e-9, sh.p1, sh.p2);
+    }
   }
 
   if (all || !strcmp(what, "percu")) {
