@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclfft_amd.so")
+# (CLFA_LIB_PATH: another build of the same library, for A/B runs of bench.py — tools/build_variant.sh)
+LIB_PATH = os.environ.get("CLFA_LIB_PATH") or os.path.join(_HERE, "libclfft_amd.so")
 
 # every symbol include/clfft_amd.h declares: (name, restype, argtypes)
 _vp, _fp, _ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)

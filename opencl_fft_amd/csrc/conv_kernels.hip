@@ -611,43 +611,54 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
   __syncthreads();
 
   // ---- forward chain(s) in every workgroup: reference reorder + fft + r2c (cl_conv.cpp:399-419 / 465-513) ----
-  auto forward = [&](const float *in, cpx *ring, int frame, cpx *sf) {
+  // Time-varying blocks transform both inputs AT ONCE where the lanes allow it (2 T <= 256): lanes [0, T) take in1,
+  // lanes [T, 2 T) in2, each group with its own exchange buffer — one pass chain's worth of barriers, not two.
+  constexpr bool DUAL = TV && 2 * T <= 256;
+  __shared__ cpx s_x2[DUAL ? G::PADN : 1];
+  auto forward = [&](const float *inA, const float *inB, bool dual) {
+    // inB / ring B only when dual; otherwise one input (inA) by lanes [0, T)
+    const int grp = dual ? tid / T : 0, tt = dual ? tid % T : tid;
+    const bool work = dual ? tid < 2 * T : tid < T;
+    cpx *sx = (DUAL && grp == 1) ? s_x2 : s_x;
     cpx v[E];
-    if (tid < T) {
-      const cpx *src = reinterpret_cast<const cpx *>(in + (long)ch * N);
+    if (work) {
+      const cpx *src = reinterpret_cast<const cpx *>((grp == 1 ? inB : inA) + (long)ch * N);
 #pragma unroll
       for (int e = 0; e < E; e++) {
-        const int p = tid + T * e;
+        const int p = tt + T * e;
         v[e] = p < N / 2 ? src[p] : mk(0.f, 0.f);
       }
-      pass_compute<LOGB, G::LOGE, 0, true>(v, tid, s_tab);
+      pass_compute<LOGB, G::LOGE, 0, true>(v, tt, s_tab);
     }
     __syncthreads();
-    if (tid < T) pass_scatter<LOGB, G::LOGE, 0>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+    if (work) pass_scatter<LOGB, G::LOGE, 0>(v, tt, [&](int p, cpx val) { sx[lds_pad(p)] = val; });
     __syncthreads();
-    if (tid < T) {
-      pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
-      pass_compute<LOGB, G::LOGE, 4, true>(v, tid, s_tab);
+    if (work) {
+      pass_gather<LOGB, G::LOGE>(v, tt, [&](int p) { return sx[lds_pad(p)]; });
+      pass_compute<LOGB, G::LOGE, 4, true>(v, tt, s_tab);
     }
     if constexpr (LOGB > 8) {
       __syncthreads();
-      if (tid < T) pass_scatter<LOGB, G::LOGE, 4>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+      if (work) pass_scatter<LOGB, G::LOGE, 4>(v, tt, [&](int p, cpx val) { sx[lds_pad(p)] = val; });
       __syncthreads();
-      if (tid < T) {
-        pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
-        pass_compute<LOGB, G::LOGE, 8, true>(v, tid, s_tab);
+      if (work) {
+        pass_gather<LOGB, G::LOGE>(v, tt, [&](int p) { return sx[lds_pad(p)]; });
+        pass_compute<LOGB, G::LOGE, 8, true>(v, tt, s_tab);
       }
     }
     __syncthreads();
-    if (tid < T) {
+    if (work) {
 #pragma unroll
-      for (int e = 0; e < E; e++) s_x[lds_pad(tid + T * e)] = v[e];
+      for (int e = 0; e < E; e++) sx[lds_pad(tt + T * e)] = v[e];
     }
     __syncthreads();
+  };
+  // packed spectrum (reference r2c) of the transform left in `sx` -> sf (LDS) and, by workgroup 0, the ring frame
+  auto pack = [&](const cpx *sx, cpx *ring, int frame, cpx *sf) {
     cpx *x = ring + ((long)ch * nparts + frame) * N;
     for (int i = tid; i < N / 2; i += 256) {
       const int j = i == 0 ? N / 2 : N - i;
-      const cpx ci = s_x[lds_pad(i)], cj = s_x[lds_pad(j)];
+      const cpx ci = sx[lds_pad(i)], cj = sx[lds_pad(j)];
       cpx oi, oj;
       r2c_pair(ci, cj, w2f_g[i], oi, oj);
       if (i == 0) {
@@ -661,10 +672,22 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
         x[j] = oj;
       }
     }
-    __syncthreads();
   };
-  forward(in1, ringA, frame1, s_fa);
-  if constexpr (TV) forward(in2, ringB, frame2, s_fb);
+  if constexpr (DUAL) {
+    forward(in1, in2, true);
+    pack(s_x, ringA, frame1, s_fa);
+    pack(s_x2, ringB, frame2, s_fb);
+    __syncthreads();
+  } else {
+    forward(in1, nullptr, false);
+    pack(s_x, ringA, frame1, s_fa);
+    __syncthreads();
+    if constexpr (TV) {
+      forward(in2, nullptr, false);
+      pack(s_x, ringB, frame2, s_fb);
+      __syncthreads();
+    }
+  }
 
   // ---- MAC over all partitions for this workgroup's slice of the bins (reference convol, cl_conv_kernels.h:102-118)
   // slice = N >> logs bins = IW 16-byte items; lane = item li of partition row pr; rows walk p = pr, pr + NR, ...

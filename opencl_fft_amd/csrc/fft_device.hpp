@@ -635,6 +635,25 @@ CLFA_HD void c2r_pair(cpx ci, cpx cjraw, cpx w, cpx &oi, cpx &oj) {
   oj = cconj(csub(e, p));
 }
 
+// The same maps with their factors of 1/2 folded away (powers of two: bit-identical results).  r2c: the caller has
+// scaled both inputs by 1/2 (together with its 1/N); c2r: the pair twiddle comes halved (wh = w / 2).
+CLFA_HD void r2c_pair_prescaled(cpx ci, cpx cjraw, cpx w, cpx &oi, cpx &oj) {
+  cpx cj = cconj(cjraw);
+  cpx e = cadd(ci, cj);
+  cpx d = csub(cj, ci);
+  cpx p = cmul(w, mk(-d.y, d.x));
+  oi = cadd(e, p);
+  oj = cconj(csub(e, p));
+}
+CLFA_HD void c2r_pair_halfw(cpx ci, cpx cjraw, cpx wh, cpx &oi, cpx &oj) {
+  cpx cj = cconj(cjraw);
+  cpx e = cscale(cadd(ci, cj), .5f);
+  cpx d = csub(ci, cj);
+  cpx p = cmul(wh, mk(-d.y, d.x));
+  oi = cadd(e, p);
+  oj = cconj(csub(e, p));
+}
+
 // The pair maps combine bins i and M-i of an M-point complex transform.  In the remainder pass
 // (radix R < 2^LOGE, U = E/R >= 2 butterflies per lane, NB = M/R butterflies in all) butterfly j
 // touches positions j + NB*t, and M - (j + NB*t) = (NB - j) + NB*(R-1-t): a lane that takes

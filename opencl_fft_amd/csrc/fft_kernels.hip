@@ -206,13 +206,18 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   // derive from ONE lane constant (g0 = w2[t]) times compile-time constants W_32^u, the partners being
   // -+i conj(.) — 2 VGPRs across the batch loop instead of 16 (the kernel runs under a 128-VGPR cap)
   constexpr bool W2LANE = TWO && PAIRED;
+  // the pair maps' factors of 1/2 folded away (fft_device.hpp, r2c_pair_prescaled / c2r_pair_halfw): the forward
+  // kernel scales its 16 values by 1 / (2N) instead of 1/N, the inverse kernel keeps its pair twiddles halved
+  constexpr bool HALFW = MODE == MODE_C2R && PAIRED && LOGN != 14;   // (pair_tw14 carries unscaled constants for lane 0)
+  constexpr bool PRESC = MODE == MODE_R2C && PAIRED;
+  constexpr float wsc = HALFW ? 0.5f : 1.0f;
   cpx w2r[W2LANE ? 1 : NP];
   if constexpr (W2LANE) {
-    w2r[0] = w2_g[t];
+    w2r[0] = cscale(w2_g[t], wsc);
   } else if constexpr (MODE != MODE_C2C) {
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-      if constexpr (PAIRED) w2r[k] = w2_g[pair_index<LOGN, G::LOGE>(t, k / RREM, k % RREM)];
+      if constexpr (PAIRED) w2r[k] = cscale(w2_g[pair_index<LOGN, G::LOGE>(t, k / RREM, k % RREM)], wsc);
       else w2r[k] = w2_g[t + T * k];
     }
   }
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       if (u == 3) w = ctw<FWD>(w, c32[3], s32[3]);
       if (k & 1) {
         w = FWD ? mk(-w.y, -w.x) : mk(w.y, w.x);   // W^(4096 - i) = -i conj(W^i) (forward sign), +i conj (inverse)
-        if (k == 1 && lane == 0) w = mk(kC8, FWD ? -kC8 : kC8);
+        if (k == 1 && lane == 0) w = mk(kC8 * wsc, (FWD ? -kC8 : kC8) * wsc);
       }
       return w;
     } else {
@@ -273,7 +278,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {
         const int i = pair_index<LOGN, G::LOGE>(t, k / RREM, k % RREM);
-        c2r_pair(v[2 * k], v[2 * k + 1], w2_of(k, t), oi[k], oj[k]);
+        if constexpr (HALFW) c2r_pair_halfw(v[2 * k], v[2 * k + 1], w2_of(k, t), oi[k], oj[k]);
+        else c2r_pair(v[2 * k], v[2 * k + 1], w2_of(k, t), oi[k], oj[k]);
         if (k == 0) {   // lane 0: packed DC/Nyquist, bin N/2 copied through (selects, not a branch)
           const bool z = i == 0;
           oi[0] = mk(z ? v[0].x + v[0].y : oi[0].x, z ? v[0].x - v[0].y : oi[0].y);
@@ -313,8 +319,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       else wg_passes<LOGN, G::LOGE, 0, FWD, PL>(v, t, tab1, xb);
     }
 
-    if constexpr (SCALE) {
-      constexpr float inv = 1.0f / (float)N;
+    if constexpr (SCALE || PRESC) {
+      constexpr float inv = (SCALE ? 1.0f / (float)N : 1.0f) * (PRESC ? 0.5f : 1.0f);
 #pragma unroll
       for (int e = 0; e < E; e++) v[e] = cscale(v[e], inv);
     }
@@ -330,10 +336,10 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       pairs_visit<LOGN, G::LOGE>(v, t, [&](int k, int i, cpx ci, cpx cj) {
         const int j = i == 0 ? N / 2 : N - i;
         cpx oi, oj;
-        r2c_pair(ci, cj, w2_of(k, t), oi, oj);
+        r2c_pair_prescaled(ci, cj, w2_of(k, t), oi, oj);   // (ci, cj carry the map's 1/2 already)
         if (k == 0 && i == 0) {   // packed DC/Nyquist; bin N/2 copied through
-          oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
-          oj = cj;
+          oi = mk(ci.x + ci.y, ci.x - ci.y);
+          oj = cscale(cj, 2.0f);
         }
         if constexpr (kLdsBufAddr<LOGN, MODE>) {
           const auto o = pair_off<LOGN, G::LOGE>(xo, t, k / RREM, k % RREM);
