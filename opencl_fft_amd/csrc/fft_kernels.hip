@@ -73,6 +73,14 @@ template <int LOGN> __device__ __forceinline__ XferBuf xfer_buf(const cpx *x, in
 // alternating r2c / c2r, 1 GiB): size 16384 0.2054 -> 0.1974 ms (5.23 -> 5.44 TB/s) with both directions' loads plain,
 // 0.2012 / 0.2027 with one of them; sizes 8192 and 32768 within 1 %.  (The complex kernels lose 2-9 % with plain
 // loads and 3-8 % with plain stores: they keep non-temporal both ways — profiles/ab_cache_policy_r03.txt.)
+// The same holds for the persistent four-step kernel (n = 2^14, 2^15: 4.80 -> 4.83, 4.82 -> 4.93 TB/s) and for packed
+// real size 65536 (k_rfft_lds15: 3.80 -> 3.96 TB/s): plain loads, non-temporal stores.
+#ifndef CLFA_NT_LD_4STEP
+#define CLFA_NT_LD_4STEP 0
+#endif
+#ifndef CLFA_NT_LD_R15
+#define CLFA_NT_LD_R15 0
+#endif
 #ifndef CLFA_NT_LD_R2C
 #define CLFA_NT_LD_R2C 0
 #endif
@@ -343,8 +351,15 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
         }
         if constexpr (kLdsBufAddr<LOGN, MODE>) {
           const auto o = pair_off<LOGN, G::LOGE>(xo, t, k / RREM, k % RREM);
+#ifdef CLFA_EXP_SKIP_BOUNDARY   // timing experiment (wrong results): the descending streams without the element that
+          // falls into the neighbouring wave's 512-byte block (lane 0 of every wave)
+          const bool desc_i = (k % RREM) >= RREM / 2;
+          if (!desc_i || (t & 63) != 0) st_buf(xo, o.vi, o.si, oi);
+          if (desc_i || (t & 63) != 0) st_buf(xo, o.vj, o.sj, oj);
+#else
           st_buf(xo, o.vi, o.si, oi);
           st_buf(xo, o.vj, o.sj, oj);
+#endif
         } else {
           st_nt(x + i, oi);
           st_nt(x + j, oj);
@@ -411,8 +426,17 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
 // radix-2 step that joins them and the reference's pair map (cl_fft.cpp:178-205) meet in registers
 // (fft_device.hpp, rfft15_fwd_slot / rfft15_inv_slot): one HBM pass, where the four-step kernel plus the
 // stand-alone pack kernel took two.  The inverse runs the transposed network.
-__device__ __forceinline__ f4v ld_nt16(const cpx *p) { return __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)); }
-__device__ __forceinline__ void st_nt16(cpx *p, f4v v) { __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(p)); }
+__device__ __forceinline__ f4v ld_nt16(const cpx *p) {
+  return CLFA_NT_LD_R15 ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)) : *reinterpret_cast<const f4v *>(p);
+}
+__device__ __forceinline__ cpx ld_r15(const cpx *p) {
+  if (CLFA_NT_LD_R15) return ld_nt(p);
+  return *p;
+}
+__device__ __forceinline__ void st_nt16(cpx *p, f4v v) {
+  if (CLFA_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(p));
+  else *reinterpret_cast<f4v *>(p) = v;
+}
 
 template <bool FWD, bool SCALE>
 __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
@@ -475,8 +499,8 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {   // (left to the scheduler: with the loads fenced off first the prologue spills more)
         const int i = pair_index<LOGN, LOGE>(t, k / R, k % R);
-        rfft15_inv_slot(t, k / R, k % R, i, g0, h0, ld_nt(x + rfft15_pos(i, 0)), ld_nt(x + rfft15_pos(i, 1)),
-                        ld_nt(x + rfft15_pos(i, 2)), ld_nt(x + rfft15_pos(i, 3)), oa[k], pa[k], ob[k], pb[k]);
+        rfft15_inv_slot(t, k / R, k % R, i, g0, h0, ld_r15(x + rfft15_pos(i, 0)), ld_r15(x + rfft15_pos(i, 1)),
+                        ld_r15(x + rfft15_pos(i, 2)), ld_r15(x + rfft15_pos(i, 3)), oa[k], pa[k], ob[k], pb[k]);
       }
       constexpr int L1 = pass_last_logns(LOGN, LOGE) - LOGE;
       pass_first_paired<LOGN, LOGE, false>(va, t, oa, pa, tab);
@@ -738,7 +762,8 @@ __device__ __forceinline__ gptr sgpr_base(const cpx *p) {
 // streaming mode: 0 plain, 1 non-temporal, 2 system scope (sc0 sc1), 3 agent scope (sc1: bypasses the CU's L1)
 template <int SM> __device__ __forceinline__ cpx ld_g(gcptr p) {
   unsigned long long raw;
-  if constexpr (SM == 1) raw = __builtin_nontemporal_load(p);
+  if constexpr (SM == 1 && CLFA_NT_LD_4STEP) raw = __builtin_nontemporal_load(p);
+  else if constexpr (SM == 1) raw = *p;
   else if constexpr (SM == 2) raw = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   else if constexpr (SM == 3) raw = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else raw = *p;
@@ -746,7 +771,8 @@ template <int SM> __device__ __forceinline__ cpx ld_g(gcptr p) {
 }
 template <int SM> __device__ __forceinline__ void st_g(gptr p, cpx v) {
   const unsigned long long raw = *reinterpret_cast<const unsigned long long *>(&v);
-  if constexpr (SM == 1) __builtin_nontemporal_store(raw, p);
+  if constexpr (SM == 1 && CLFA_NT_ST) __builtin_nontemporal_store(raw, p);
+  else if constexpr (SM == 1) *p = raw;
   else if constexpr (SM == 2) __hip_atomic_store(p, raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   else *p = raw;
 }

@@ -559,6 +559,7 @@ __device__ __forceinline__ void res_phase1_block(cpx (&v)[16], const ResLane &L,
 
 }  // namespace
 
+#ifdef CLFA_RES16_PROBE
 // probe only: all workgroups meet (monotonic counter; bounded spin)
 __device__ __forceinline__ void res_probe_grid_sync(unsigned long long *dbg, unsigned &epoch) {
   __syncthreads();
@@ -573,12 +574,16 @@ __device__ __forceinline__ void res_probe_grid_sync(unsigned long long *dbg, uns
   }
   __syncthreads();
 }
+#endif
 
 // slots: one 32 KiB slot per workgroup (the single row block that does not fit the CU)
 template <bool FWD, bool SCALE, int PROBE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_fft_res16(cpx *__restrict__ data, cpx *__restrict__ slots,
                                                    const cpx *__restrict__ tabs_g, long batch,
                                                    unsigned long long *__restrict__ dbg = nullptr) {
+#ifndef CLFA_RES16_PROBE
+  static_assert(PROBE == 0, "the timing experiments exist only in tools/res16_probe.hip (CLFA_RES16_PROBE)");
+#endif
   __shared__ __attribute__((aligned(16))) cpx s_tab[kTabSize];
   __shared__ __attribute__((aligned(16))) cpx s_x[kXSize];
   __shared__ __attribute__((aligned(16))) char s_spill[256 * kSpillStride];
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
   for (int j = 0; j < kVgprBlk; j++) K[j] = 0.f;
   cpx v[16];
   long b = blockIdx.x;
+#ifdef CLFA_RES16_PROBE
   unsigned long long clk1 = 0, clk2 = 0;
   unsigned epoch = 0;   // probe only (the host zeroes the counter before the launch)
   unsigned long long slot_next = 0, slot_p1 = 0, slot_p2 = 0;   // probe only
@@ -631,6 +637,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     slot_p1 = dbg[2048];
     slot_p2 = dbg[2049];
   }
+#endif
   // blocks 0 and 1 of the first transform
   if constexpr (!(PROBE & kProbeNoLoad)) {
     const ResLane L0 = lane();
@@ -640,8 +647,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
 #pragma unroll 1
   for (; b < batch; b += gridDim.x) {
     cpx *x = data + b * (long)kN;
+#ifdef CLFA_RES16_PROBE
     unsigned long long t0 = 0;
     if constexpr (PROBE & kProbeStamps) t0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- phase 1: four column blocks per round (landing zones Z0, v[224:255], Z1, v[224:255]); on entry
     // block 0 is in (or on its way to) Z0 and block 1 on its way to the landing registers
 #pragma unroll 1
@@ -655,6 +664,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     res_phase1_block<FWD, PROBE, -1, -1, true>(v, lane(), x, 13, rot, so, K, slot, s_tab, s_x);
     res_phase1_block<FWD, PROBE, kZone1, -1, false>(v, lane(), x, 14, rot, so, K, slot, s_tab, s_x);
     res_phase1_block<FWD, PROBE, -1, -1, false, 0, true>(v, lane(), x, 15, rot, so, K, slot, s_tab, s_x);
+#ifdef CLFA_RES16_PROBE
     if constexpr (PROBE & kProbeStamps) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
       clk1 += t1 - t0;
@@ -669,6 +679,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       while ((long long)(__builtin_amdgcn_s_memrealtime() - slot_next) < 0) __builtin_amdgcn_s_sleep(8);
       if constexpr (PROBE & kProbeStamps) t0 = __builtin_amdgcn_s_memtime();
     }
+#endif
     // ---- phase 2: row blocks in the order slot (its data are in the landing registers by now), AGPR
     // (the accumulation file is then free for the next transform's block 0), VGPR, LDS.  A block's results
     // are parked in the landing registers and stored while the next block is computed.
@@ -717,19 +728,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       // the next transform's block 1 -> landing registers (after this block's parked stores have been issued)
       if constexpr (!(PROBE & kProbeNoLoad)) res_load_land(xn + ((1 + rot) & 15) * 16, L.voff);
     }
+#ifdef CLFA_RES16_PROBE
     if constexpr (PROBE & kProbeStamps) clk2 += __builtin_amdgcn_s_memtime() - t0;
     if constexpr (PROBE & kProbeGridSync) res_probe_grid_sync(dbg, epoch);
     if constexpr (PROBE & kProbeSlots) {
       slot_next += slot_p2;
       while ((long long)(__builtin_amdgcn_s_memrealtime() - slot_next) < 0) __builtin_amdgcn_s_sleep(8);
     }
+#endif
   }
+#ifdef CLFA_RES16_PROBE
   if constexpr (PROBE & kProbeStamps) {
     if (tid == 0) {
       dbg[2 * blockIdx.x] = clk1;
       dbg[2 * blockIdx.x + 1] = clk2;
     }
   }
+#endif
 }
 
 hipError_t launch_fft_res16(bool fwd, bool scale, cpx *data, cpx *slots, const cpx *tabs, long batch,

@@ -105,6 +105,42 @@ def test_bench_two_rank_rehearsal():
     assert abs(r["value"] - expect) / expect < 1e-6
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without an outer launcher: bench.py spawns torch.distributed.run itself (before it
+    touches the GPU) and relays rank 0's line; rehearsed on one GPU (gloo, both ranks on device 0)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CLFA_BENCH_BACKEND="gloo", CLFA_BENCH_DEVICE="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--batch", "256"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    assert p.returncode == 0
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout.decode()
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 512 and r["cpu_baseline"] is None
+    assert "other_workloads" not in r["config"] and r["ms_per_step_cold"] > 0
+
+
+def test_bench_default_line_carries_every_single_gpu_config():
+    """the driver's command line (no --workload, no --batch): the headline (configs[1]) with its cold figure beside it,
+    configs[2] and configs[3] under config.other_workloads, each with its own roofline block"""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2"],
+                                  stderr=subprocess.DEVNULL, timeout=900).decode()
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    r = json.loads(line[0])
+    assert r["steps"] == 6 and r["warmup"] == 2 and "4096 batches" in r["config"]["workload"]
+    assert r["ms_per_step_cold"] > 0 and 0 < r["roofline"]["frac_cold"] < 1 and 0 < r["roofline"]["frac"] < 1
+    assert r["config"]["effective_warmup_launches"] >= 2 * 2 + 6 + 4
+    ow = r["config"]["other_workloads"]
+    assert set(ow) == {"rfft", "pconv"}
+    for k, v in ow.items():
+        assert v["ms_per_step"] > 0 and v["steps"] >= 100 and 0 < v["roofline"]["frac"] < 1 and v["roofline"]["kernel"]
+        assert v["roofline"]["bound"] == "hbm" and v["roofline"]["peak"] == 8000.0
+    assert ow["pconv"]["realtime_ratio"] > 50 and "BASELINE configs[3]" in ow["pconv"]["workload"]
+    assert "BASELINE configs[2]" in ow["rfft"]["workload"] and ow["rfft"]["full_size_selfcheck"]["roundtrip_max_abs"] < 2e-5
+    assert r["cpu_baseline"]["kind"] == "port"
+
+
 def test_device_entry_points_capture_into_a_hip_graph():
     """the launch path neither allocates nor synchronises, so a sequence of transforms on a caller
     stream can be captured once and replayed (hipGraph via torch.cuda.CUDAGraph)"""

@@ -57,3 +57,17 @@ for r in range(9):
 for k, t in times.items():
     m = statistics.median(t)
     print("%s: median %.4f ms  min %.4f ms  alg %.2f TB/s" % (k, m, min(t), unit / m / 1e9))
+# per direction (an event after every launch keeps launches from running back to back: slower than the figures above)
+per = {k: ([], []) for k in libs}
+for r in range(5):
+    for k, (lib, ps) in libs.items():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+        ev[0].record()
+        for j in range(10):
+            assert lib.clfa_fft_exec_dev(ps[j % 2], d.data_ptr(), batch, s) == 0
+            ev[j + 1].record()
+        torch.cuda.synchronize()
+        for j in range(10):
+            per[k][j % 2].append(ev[j].elapsed_time(ev[j + 1]))
+for k, (f, i) in per.items():
+    print("%s: forward median %.4f ms   inverse median %.4f ms  (event per launch)" % (k, statistics.median(f), statistics.median(i)))

@@ -2,6 +2,7 @@
 //   hipcc -std=c++17 -O3 --offload-arch=gfx950 -fno-slp-vectorize -I opencl_fft_amd/csrc tools/res16_probe.hip -o /tmp/res16_probe
 // Times k_fft_res16 on 4096 transforms with parts left out (PROBE bits, fft_resident.hip) and reads the
 // per-phase clock stamps.  Results are garbage by construction for every mode but "full".
+#define CLFA_RES16_PROBE 1   // the kernel's timing experiments (stamps, grid barrier, time slots) exist only in this tool
 #include "../opencl_fft_amd/csrc/fft_resident.hip"
 
 #include <unistd.h>

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_model2(char *data, long mats, unsigned 
 // group is transformed (one per hook).  QL / QS: order inside a group — true: row-major (row e of blocks g = 0..GQ-1
 // back to back: GQ adjacent 128-byte segments = GQ x 128 contiguous bytes requested together), false: block-major
 // (the same blocks in flight, but adjacent segments a block's length apart in time).
-template <int W, int GQ, int LPH, bool QL, bool QS, bool XCHG, int MODE = 0, int POFF = 0>
+template <int W, int GQ, int LPH, bool QL, bool QS, bool XCHG, int MODE = 0, int POFF = 0, bool EARLY = false>
 __global__ __launch_bounds__(256) void k_model3(char *data, long mats, unsigned long long *dbg, float *sink) {
   __shared__ f2 sx[16 * 258 + 64];
   constexpr bool NOLD = MODE & 1, NOST = MODE & 2;
@@ -340,9 +340,14 @@ __global__ __launch_bounds__(256) void k_model3(char *data, long mats, unsigned 
       [&]<int... H>(std::integer_sequence<int, H...>) {
         auto hook = [&](auto hc) {
           constexpr int h = decltype(hc)::value, gg = h / 16, k = h % 16;
+          if constexpr (EARLY && k == 0) {   // the real kernel takes ALL 16 rows of a block out of their landing zone at its start
+#pragma unroll
+            for (int e = 0; e < 16; e++) A.a[e & 7] += cur[gg][e];
+            __builtin_amdgcn_sched_barrier(0);
+          }
           busy<W>(A);
           if constexpr (k == 7 && XCHG) xchg(cur[gg], sx);
-          A.a[k & 7] += cur[gg][k];
+          if constexpr (!EARLY) A.a[k & 7] += cur[gg][k];
           __builtin_amdgcn_sched_barrier(0);
           [&]<int... I>(std::integer_sequence<int, I...>) { (issue_load(ic<h * LPH + I>(), xl, gl, g), ...); }(std::make_integer_sequence<int, LPH>());
           __builtin_amdgcn_sched_barrier(0);
@@ -737,6 +742,46 @@ int main(int argc, char **argv) {
       std::vector<float> v = sh.ms;
       std::sort(v.begin(), v.end());
       printf("%-30s %7.3f ms (min %.3f)  %5.2f TB/s   p1 %5.1f  p2 %5.1f\n", sh.name, v[v.size() / 2], v.front(),
+             by / v[v.size() / 2] * 1e-9, sh.p1, sh.p2);
+    }
+  }
+
+  if (!strcmp(what, "model3c")) {
+    printf("\n[model3c] pairs by rows when a block needs ALL its rows at its start (as the real kernel does: early = 1)\n");
+    struct Shape {
+      char name[112];
+      std::function<void()> launch;
+      std::vector<float> ms;
+      double p1, p2;
+    };
+    std::vector<Shape> shapes;
+#define M3C(W, GQ, LPH, QL, QS, EARLY)                                                                                    \
+  {                                                                                                                       \
+    Shape s;                                                                                                              \
+    snprintf(s.name, sizeof s.name, "GQ %d  W %2d  loads/hook %d  loads by %-6s stores by %-6s early %d", GQ, W, LPH,     \
+             QL ? "rows" : "blocks", QS ? "rows" : "blocks", (int)EARLY);                                                 \
+    s.launch = [=] { hipLaunchKernelGGL((k_model3<W, GQ, LPH, QL, QS, true, 0, 0, EARLY>), dim3(cus), dim3(256), 0, 0, a, mats, dbg, sink); }; \
+    shapes.push_back(s);                                                                                                  \
+  }
+    M3C(22, 1, 1, false, false, false) M3C(22, 1, 1, false, false, true) M3C(22, 2, 1, false, false, true) M3C(22, 2, 1, true, true, true)
+    M3C(22, 2, 1, true, false, true) M3C(22, 2, 1, false, true, true) M3C(22, 2, 1, true, true, false) M3C(22, 4, 1, true, true, true)
+    for (int round = 0; round < 5; round++)
+      for (auto &sh : shapes) {
+        sh.ms.push_back(time_launches(6, 30, sh.launch));
+        CK(hipMemcpy(hdbg.data(), dbg, 2 * cus * 8, hipMemcpyDeviceToHost));
+        double s1 = 0, s2 = 0;
+        for (int i = 0; i < cus; i++) {
+          s1 += hdbg[2 * i];
+          s2 += hdbg[2 * i + 1];
+        }
+        sh.p1 = s1 / mats * 1e-3;
+        sh.p2 = s2 / mats * 1e-3;
+      }
+    const double by = 2.0 * (double)mats * 524288;
+    for (auto &sh : shapes) {
+      std::vector<float> v = sh.ms;
+      std::sort(v.begin(), v.end());
+      printf("%-86s %7.3f ms (min %.3f)  %5.2f TB/s   p1 %5.1f  p2 %5.1f\n", sh.name, v[v.size() / 2], v.front(),
              by / v[v.size() / 2] * 1e-9, sh.p1, sh.p2);
     }
   }
