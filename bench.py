@@ -307,6 +307,11 @@ def main():
             wl.run(W)
         cold_s, cold_ms, _ = wl.timed(K, barrier)
         cold = {"ms_per_step": cold_s / K * 1e3, "avg_launch_ms": cold_ms}
+    elif not a.no_selfcheck and not a.series_out:
+        # (profiling runs, --no-cold: the guard's transforms would otherwise be the first launches of the process, at
+        # start-up clocks, and weigh on the per-kernel averages of rocprofv3 --stats)
+        with torch.cuda.stream(stream):
+            wl.run(W)
     # 2. the full-size guard (~15 launch-equivalents of device work with its elementwise kernels)
     if not a.no_selfcheck:
         chk = wl.selfcheck()

@@ -835,8 +835,8 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
 // Shape of the cooperative block, or logs = -1 when it does not apply: bins 512..4096; slices of 32 bins (256-byte
 // segments of a frame) unless the channels alone would overfill the chip; the partition axis cut into segments until
 // a workgroup's share of the two rings is at most CLFA_PCONV_COOP_MAX_KB (tuning switch, read once; 0 switches the
-// kernel off), as far as one workgroup per CU goes; shares beyond 4 x that stay with the launch chain above (the
-// split MAC + tree sum), which puts the whole chip on the partition axis.
+// kernel off); filters that would need more than half the CUs that way stay with the launch chain above (the split
+// MAC + tree sum), which puts the whole chip on the partition axis.
 PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di) {
   static const long cap_kb = [] {
     const char *e = getenv("CLFA_PCONV_COOP_MAX_KB");
@@ -850,11 +850,15 @@ PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di) {
   if (((long)g.channels << logs) > 2L * di.num_cus) return c;
   const long share = 2L * g.nparts * (g.bins >> logs) * 8;   // bytes of the rings one bin slice streams
   long sparts = (share + cap_kb * 1024 - 1) / (cap_kb * 1024);
-  const long room = di.num_cus / ((long)g.channels << logs);
-  if (sparts > room) sparts = room;
+  // ... as far as HALF the CUs go: a block that needs the whole chip to stream its rings is faster on the chain
+  // (measured, real-time ratio of one time-varying channel: M = 512, L = 2^21: 448 here against 482 on the chain,
+  // L = 2^22: 384 / 401; M = 2048, L = 2^21: 1761 / 1804 — every workgroup repeats the forward transform, and
+  // the last one adds up all the segments)
+  long room = (di.num_cus / 2) / ((long)g.channels << logs);
+  if (room < 1) room = 1;
   if (sparts > g.nparts / 4) sparts = g.nparts / 4;          // segments of at least 4 partitions
   if (sparts < 1) sparts = 1;
-  if (share / sparts > 4 * cap_kb * 1024) return c;
+  if (sparts > room) return c;
   c.logs = logs;
   c.sparts = (int)sparts;
   return c;

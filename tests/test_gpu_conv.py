@@ -321,7 +321,7 @@ def test_pconv_push_ir_device_ragged_cvs():
                                                           (4096, 3, 1, 8, True), (1024, 94, 2, 100, False),
                                                           (4096, 2, 40, 5, False),
                                                           # long filters: the partition axis cut into segments as well
-                                                          (512, 600, 1, 8, True), (1024, 1000, 2, 6, False),
+                                                          (512, 600, 1, 8, True), (1024, 400, 2, 6, False),
                                                           (512, 2048, 1, 5, False)])
 def test_pconv_cooperative_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
     """few channels: one cooperative launch per block (k_pconv_coop: the bins of the multiply-accumulate split over
