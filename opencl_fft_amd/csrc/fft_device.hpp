@@ -719,8 +719,13 @@ template <int R> CLFA_HD void pair_unperm_lane0(bool lane0, cpx (&m)[R], cpx (&p
 // Forward: the LAST (remainder) pass of an M-point transform, butterflies paired as above; gathers
 // from the padded exchange buffer.  Afterwards slot u + U*q holds Z[j + NB*q] and slot
 // u + U/2 + U*q holds Z[jp + NB*q], jp = NB - j (NB/2 for j = 0).
-template <int LOGN, int LOGE, bool FWD, class Tab>
-CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, const cpx *xb) {
+struct NoMid {
+  CLFA_HD void operator()() const {}
+};
+// mid(): called between the gather from the exchange buffer and the arithmetic (wg_passes_pair: the other
+// transform's scatter goes there, so that its LDS transfer runs under this pass's butterflies)
+template <int LOGN, int LOGE, bool FWD, class Tab, class Mid = NoMid>
+CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, const cpx *xb, const Mid &mid = Mid()) {
   static_assert(pair_ok(LOGN, LOGE), "needs a remainder pass with two butterflies per lane");
   constexpr int LOGR = pass_rem_logr(LOGN, LOGE), R = 1 << LOGR, E = 1 << LOGE, U = E / R;
   constexpr int T = 1 << (LOGN - LOGE), NB = 1 << (LOGN - LOGR);
@@ -743,6 +748,7 @@ CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, cons
       }
     }
     if constexpr (!is_lane_tab<Tab>::value) {
+      static_assert(std::is_same<Mid, NoMid>::value, "mid hook: lane-table twiddles only (they follow the whole gather)");
 #pragma unroll
       for (int t = 1; t < R; t++) {
         v[u + U * t] = cmul_tw<LOGN, FWD>(v[u + U * t], tab, j * t);
@@ -750,6 +756,7 @@ CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, cons
       }
     }
   }
+  mid();
   if constexpr (is_lane_tab<Tab>::value) lane_tw_paired<FWD>(v, tid, tab);
 #pragma unroll
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);

@@ -469,8 +469,13 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
         va[e] = mk(q.x, q.y);
         vb[e] = mk(q.z, q.w);
       }
+#ifdef CLFA_R15_SERIAL   // A/B switch: the two chains one after the other (round 2)
       wg_passes<LOGN, LOGE, 0, true, true>(va, t, tab, xb);
       wg_passes<LOGN, LOGE, 0, true, true>(vb, t, tab, xb);
+#else
+      pass_compute<LOGN, LOGE, 0, true>(va, t, tab);
+      wg_passes_pair<LOGN, LOGE, 0, true>(va, vb, t, tab, xb);   // staggered: one chain's LDS transfers under the other's passes
+#endif
       if constexpr (SCALE) {
         constexpr float inv = 1.0f / (float)(2 * kM15);
 #pragma unroll
@@ -503,6 +508,7 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
                         ld_r15(x + rfft15_pos(i, 2)), ld_r15(x + rfft15_pos(i, 3)), oa[k], pa[k], ob[k], pb[k]);
       }
       constexpr int L1 = pass_last_logns(LOGN, LOGE) - LOGE;
+#ifdef CLFA_R15_SERIAL
       pass_first_paired<LOGN, LOGE, false>(va, t, oa, pa, tab);
       __syncthreads();
       pass_first_paired_scatter<LOGN, LOGE>(va, t, xb);
@@ -513,6 +519,21 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
       pass_first_paired_scatter<LOGN, LOGE>(vb, t, xb);
       __syncthreads();
       wg_passes_dif_after<LOGN, LOGE, L1, false>(vb, t, tab, xb);
+#else
+      // staggered (fft_wg.hpp, wg_passes_dif_pair): one chain's scatter drains under the other's butterflies
+      pass_first_paired<LOGN, LOGE, false>(va, t, oa, pa, tab);
+      __syncthreads();
+      pass_first_paired_scatter<LOGN, LOGE>(va, t, xb);
+      pass_first_paired<LOGN, LOGE, false>(vb, t, ob, pb, tab);
+      __syncthreads();
+      dif_gather_padded<LOGN, LOGE, L1>(va, t, xb);
+      __syncthreads();
+      pass_first_paired_scatter<LOGN, LOGE>(vb, t, xb);
+      dif_compute<LOGN, LOGE, L1, false>(va, t, tab);
+      __syncthreads();
+      dif_gather_padded<LOGN, LOGE, L1>(vb, t, xb);
+      wg_passes_dif_pair<LOGN, LOGE, L1, false>(va, vb, t, tab, xb);
+#endif
 #pragma unroll
       for (int e = 0; e < E; e++) st_nt16(x + 2 * (t + T * e), f4v{va[e].x, va[e].y, vb[e].x, vb[e].y});
     }

@@ -39,6 +39,60 @@ __device__ __forceinline__ void wg_passes_dif_after(cpx (&v)[1 << LOGE], int t, 
   }
 }
 
+// TWO independent transforms through ONE exchange buffer, staggered (packed real size 65536: the even and the odd
+// half of a transform, k_rfft_lds15): while one transform's values are on their way through LDS the other's pass is
+// computed.  Run one after the other, every wave of the workgroup does the same thing at the same time — all of them
+// compute, then all of them wait for their scattered writes to drain (16 ds_write_b64 per lane move at a third of the
+// LDS read rate), then all of them gather — and the chains, not the memory, bound the kernel.
+// Same passes, same number of barriers as two wg_passes calls.
+// Precondition: va holds the OUTPUT of pass LOGNS (computed), vb its INPUT (not yet computed); last pass paired.
+template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
+__device__ __forceinline__ void wg_passes_pair(cpx (&va)[1 << LOGE], cpx (&vb)[1 << LOGE], int t, const Tab &tab, cpx *xb) {
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS), NEXT = LOGNS + LOGR;
+  static_assert(NEXT < LOGN, "ends in pass_last_paired");
+  __syncthreads();   // everybody is done reading the previous exchange
+  pass_scatter_padded<LOGN, LOGE, LOGNS>(va, t, xb);
+  pass_compute<LOGN, LOGE, LOGNS, FWD>(vb, t, tab);          // under a's LDS writes
+  __syncthreads();
+  if constexpr (NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN) {
+    pass_last_paired<LOGN, LOGE, FWD>(va, t, tab, xb, [&]() {
+      __syncthreads();   // a's gather is complete in every wave
+      pass_scatter_padded<LOGN, LOGE, LOGNS>(vb, t, xb);     // ... and b's writes run under a's last butterflies
+    });
+    __syncthreads();
+    pass_last_paired<LOGN, LOGE, FWD>(vb, t, tab, xb);
+  } else {
+    pass_gather_padded<LOGN, LOGE>(va, t, xb);
+    __syncthreads();
+    pass_scatter_padded<LOGN, LOGE, LOGNS>(vb, t, xb);
+    pass_compute<LOGN, LOGE, NEXT, FWD>(va, t, tab);         // under b's LDS writes
+    __syncthreads();
+    pass_gather_padded<LOGN, LOGE>(vb, t, xb);
+    wg_passes_pair<LOGN, LOGE, NEXT, FWD>(va, vb, t, tab, xb);
+  }
+}
+
+// ... and the transposed chains from the pass (2^LOGNS, radix 2^LOGE) downwards.  Precondition: va has been through
+// dif_compute<LOGNS>; vb has been gathered for that pass (dif_gather_padded<LOGNS>) but not computed yet.
+template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
+__device__ __forceinline__ void wg_passes_dif_pair(cpx (&va)[1 << LOGE], cpx (&vb)[1 << LOGE], int t, const Tab &tab, cpx *xb) {
+  if constexpr (LOGNS > 0) {
+    __syncthreads();
+    dif_scatter_padded<LOGN, LOGE>(va, t, xb);
+    dif_compute<LOGN, LOGE, LOGNS, FWD>(vb, t, tab);           // under a's LDS writes
+    __syncthreads();
+    dif_gather_padded<LOGN, LOGE, LOGNS - LOGE>(va, t, xb);
+    __syncthreads();
+    dif_scatter_padded<LOGN, LOGE>(vb, t, xb);
+    dif_compute<LOGN, LOGE, LOGNS - LOGE, FWD>(va, t, tab);    // under b's LDS writes
+    __syncthreads();
+    dif_gather_padded<LOGN, LOGE, LOGNS - LOGE>(vb, t, xb);
+    wg_passes_dif_pair<LOGN, LOGE, LOGNS - LOGE, FWD>(va, vb, t, tab, xb);
+  } else {
+    dif_compute<LOGN, LOGE, 0, FWD>(vb, t, tab);
+  }
+}
+
 template <int LOGN> struct LdsGeom {
   static constexpr int N = 1 << LOGN;
   // 16 points per lane.  (32 points per lane with radix-32 passes was measured for n = 8192:
