@@ -322,7 +322,9 @@ def test_pconv_push_ir_device_ragged_cvs():
                                                           (4096, 2, 40, 5, False),
                                                           # long filters: the partition axis cut into segments as well
                                                           (512, 600, 1, 8, True), (1024, 400, 2, 6, False),
-                                                          (512, 2048, 1, 5, False)])
+                                                          (512, 2048, 1, 5, False),
+                                                          # many channels: fewer, wider bin slices per channel
+                                                          (512, 6, 100, 5, False), (2048, 3, 9, 6, True), (1024, 5, 33, 7, True)])
 def test_pconv_cooperative_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
     """few channels: one cooperative launch per block (k_pconv_coop: the bins of the multiply-accumulate split over
     the workgroups of a channel, the last workgroup to arrive runs the inverse chain).  Static and time-varying,
