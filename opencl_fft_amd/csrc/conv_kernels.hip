@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
                                                     int sparts) {
   using G = LdsGeom<LOGB>;
   constexpr int N = G::N, E = G::E, T = G::T, HB = N / 2;   // N = bins; T = N/16 lanes run the FFTs
-  static_assert(T <= 256 && N / 2 >= 256, "bins 512..4096");
+  static_assert(LOGB >= 5 && T <= 256, "bins 32..4096: slices of 32 bins, 16 points per lane in the transforms");
   __shared__ cpx s_tab[G::HALF];
   __shared__ cpx s_x[G::PADN];
   __shared__ cpx s_fa[N];               // packed spectrum of the new input block (frame1 of ring A)
@@ -630,6 +630,7 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
       }
       pass_compute<LOGB, G::LOGE, 0, true>(v, tt, s_tab);
     }
+    // (LOGB > 4 always: a second pass of radix 2^min(4, LOGB - 4), a third one above 256 bins)
     __syncthreads();
     if (work) pass_scatter<LOGB, G::LOGE, 0>(v, tt, [&](int p, cpx val) { sx[lds_pad(p)] = val; });
     __syncthreads();
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
   }
 }
 
-// Shape of the cooperative block, or logs = -1 when it does not apply: bins 512..4096; slices of 32 bins (256-byte
+// Shape of the cooperative block, or logs = -1 when it does not apply: bins 32..4096; slices of 32 bins (256-byte
 // segments of a frame) unless the channels alone would overfill the chip; the partition axis cut into segments until
 // a workgroup's share of the two rings is at most CLFA_PCONV_COOP_MAX_KB (tuning switch, read once; 0 switches the
 // kernel off); filters that would need more than half the CUs that way stay with the launch chain above (the split
@@ -843,7 +844,7 @@ PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di) {
     return e ? atol(e) : 128L;
   }();
   PconvCoop c{-1, 1};
-  if (g.logb < 9 || g.logb > 12 || cap_kb <= 0) return c;
+  if (g.logb < 5 || g.logb > 12 || cap_kb <= 0) return c;
   int logs = g.logb - 5;                                  // 32 bins per workgroup
   const int logs_min = g.logb > 9 ? g.logb - 9 : 0;       // at most 256 16-byte items per workgroup (one per lane)
   while (logs > logs_min && ((long)g.channels << logs) > di.num_cus) logs--;
@@ -885,7 +886,7 @@ hipError_t launch_pconv_coop(const PconvGeom &g, PconvCoop c, const float *in1, 
 #define CLFA_B(L) \
   case L:         \
     return launch_coop_one<L>(g, c, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, xacc, counters, s);
-    CLFA_B(9) CLFA_B(10) CLFA_B(11) CLFA_B(12)
+    CLFA_B(5) CLFA_B(6) CLFA_B(7) CLFA_B(8) CLFA_B(9) CLFA_B(10) CLFA_B(11) CLFA_B(12)
 #undef CLFA_B
     default:
       return hipErrorInvalidValue;

@@ -323,6 +323,9 @@ def test_pconv_push_ir_device_ragged_cvs():
                                                           # long filters: the partition axis cut into segments as well
                                                           (512, 600, 1, 8, True), (1024, 400, 2, 6, False),
                                                           (512, 2048, 1, 5, False),
+                                                          # partitions below 512 samples (low-latency audio blocks)
+                                                          (32, 5, 1, 12, False), (64, 9, 2, 20, True), (128, 16, 1, 10, False),
+                                                          (256, 5, 3, 14, True), (64, 1, 1, 4, False),
                                                           # many channels: fewer, wider bin slices per channel
                                                           (512, 6, 100, 5, False), (2048, 3, 9, 6, True), (1024, 5, 33, 7, True)])
 def test_pconv_cooperative_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):

@@ -30,6 +30,6 @@ def run(pts, cvs, tv, iters=300):
     dev = (time.perf_counter() - t0) / iters * 1e6
     print("pts %5d  parts %4d  %s: host call %.1f us   device-resident %.1f us per block" % (pts, c.nparts, "tv    " if tv else "static", host, dev), flush=True)
 
-for pts, cvs in [(512, 1 << 16), (512, 1 << 20), (2048, 1 << 18), (8192, 1 << 20)]:
+for pts, cvs in [(64, 1 << 13), (128, 1 << 15), (256, 1 << 16), (512, 1 << 16), (512, 1 << 20), (2048, 1 << 18), (8192, 1 << 20)]:
     for tv in (False, True):
         run(pts, cvs, tv)
