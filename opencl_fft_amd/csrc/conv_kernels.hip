@@ -588,7 +588,7 @@ __device__ __forceinline__ cpx ld_agent(const cpx *p) {
 }
 
 template <int LOGB, bool TV>
-__global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in1, const float *__restrict__ in2,
+__global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *__restrict__ in1, const float *__restrict__ in2,
                                                     cpx *__restrict__ ringA, cpx *__restrict__ ringB,
                                                     float *__restrict__ tail, float *__restrict__ out, int frame1,
                                                     int frame2, int wp, int nparts, const cpx *__restrict__ tab_g,
@@ -597,23 +597,25 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
                                                     int sparts) {
   using G = LdsGeom<LOGB>;
   constexpr int N = G::N, E = G::E, T = G::T, HB = N / 2;   // N = bins; T = N/16 lanes run the FFTs
-  static_assert(LOGB >= 5 && T <= 256, "bins 32..4096: slices of 32 bins, 16 points per lane in the transforms");
+  constexpr int WG = G::WG;                                  // 256 lanes; 512 for partitions of 8192 samples
+  constexpr int kSliceMax = 512;                             // bins per workgroup (host: logs >= LOGB - 9)
+  static_assert(LOGB >= 5 && LOGB <= 13 && T <= WG, "bins 32..8192: slices of 32 bins, 16 points per lane in the transforms");
   __shared__ cpx s_tab[G::HALF];
   __shared__ cpx s_x[G::PADN];
-  __shared__ cpx s_fa[N];               // packed spectrum of the new input block (frame1 of ring A)
-  __shared__ cpx s_fb[TV ? N : 1];      // ... of the second input (frame2 of ring B)
-  __shared__ cpx2 s_red[256];
+  __shared__ cpx s_fa[kSliceMax];            // this workgroup's slice of the new input block's packed spectrum (frame1 of ring A)
+  __shared__ cpx s_fb[TV ? kSliceMax : 1];   // ... of the second input's (frame2 of ring B)
+  __shared__ cpx2 s_red[WG];
   __shared__ int s_last;
   const int tid = threadIdx.x;
   // workgroup = (slice sl of the bins, segment ps of the partition axis)
   const int ch = blockIdx.y, S = 1 << logs, sl = blockIdx.x & (S - 1), ps = blockIdx.x >> logs;
-  for (int i = tid; i < N / 2; i += 256) s_tab[i] = tab_g[i];
+  for (int i = tid; i < N / 2; i += WG) s_tab[i] = tab_g[i];
   __syncthreads();
 
   // ---- forward chain(s) in every workgroup: reference reorder + fft + r2c (cl_conv.cpp:399-419 / 465-513) ----
   // Time-varying blocks transform both inputs AT ONCE where the lanes allow it (2 T <= 256): lanes [0, T) take in1,
   // lanes [T, 2 T) in2, each group with its own exchange buffer — one pass chain's worth of barriers, not two.
-  constexpr bool DUAL = TV && 2 * T <= 256;
+  constexpr bool DUAL = TV && 2 * T <= WG;
   __shared__ cpx s_x2[DUAL ? G::PADN : 1];
   auto forward = [&](const float *inA, const float *inB, bool dual) {
     // inB / ring B only when dual; otherwise one input (inA) by lanes [0, T)
@@ -647,6 +649,15 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
         pass_compute<LOGB, G::LOGE, 8, true>(v, tt, s_tab);
       }
     }
+    if constexpr (LOGB > 12) {
+      __syncthreads();
+      if (work) pass_scatter<LOGB, G::LOGE, 8>(v, tt, [&](int p, cpx val) { sx[lds_pad(p)] = val; });
+      __syncthreads();
+      if (work) {
+        pass_gather<LOGB, G::LOGE>(v, tt, [&](int p) { return sx[lds_pad(p)]; });
+        pass_compute<LOGB, G::LOGE, 12, true>(v, tt, s_tab);
+      }
+    }
     __syncthreads();
     if (work) {
 #pragma unroll
@@ -655,9 +666,10 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
     __syncthreads();
   };
   // packed spectrum (reference r2c) of the transform left in `sx` -> sf (LDS) and, by workgroup 0, the ring frame
+  const int bw = N >> logs, b0 = sl * bw;   // this workgroup's bins [b0, b0 + bw)
   auto pack = [&](const cpx *sx, cpx *ring, int frame, cpx *sf) {
     cpx *x = ring + ((long)ch * nparts + frame) * N;
-    for (int i = tid; i < N / 2; i += 256) {
+    for (int i = tid; i < N / 2; i += WG) {
       const int j = i == 0 ? N / 2 : N - i;
       const cpx ci = sx[lds_pad(i)], cj = sx[lds_pad(j)];
       cpx oi, oj;
@@ -666,8 +678,8 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
         oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
         oj = cj;
       }
-      sf[i] = oi;
-      sf[j] = oj;
+      if (i >= b0 && i < b0 + bw) sf[i - b0] = oi;
+      if (j >= b0 && j < b0 + bw) sf[j - b0] = oj;
       if (blockIdx.x == 0) {   // filed in the ring for the blocks to come; nobody reads it from there in this launch
         x[i] = oi;
         x[j] = oj;
@@ -693,7 +705,7 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
   // ---- MAC over all partitions for this workgroup's slice of the bins (reference convol, cl_conv_kernels.h:102-118)
   // slice = N >> logs bins = IW 16-byte items; lane = item li of partition row pr; rows walk p = pr, pr + NR, ...
   {
-    const int iw = HB >> logs, nr = 256 / iw;
+    const int iw = HB >> logs, nr = WG / iw;
     const int li = tid % iw, pr = tid / iw;
     const int item = sl * iw + li;                       // 16-byte item (bins 2 item, 2 item + 1) of the frame
     const cpx2 *a = reinterpret_cast<const cpx2 *>(ringA + (long)ch * nparts * N) + item;
@@ -735,10 +747,10 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
       term(ld_stream(a + (long)fr * HB), ld_stream(b + (long)p * HB), p != p1 && !(TV && p == frame2));
     }
     // the terms of the new frames, by the row that owns their partition
-    const cpx2 *fa = reinterpret_cast<const cpx2 *>(s_fa) + item;
+    const cpx2 *fa = reinterpret_cast<const cpx2 *>(s_fa) + li;
     if (p1 >= p_begin && p1 < p_end && pr == (p1 - p_begin) % nr) {
       cpx2 bv;
-      if (TV && p1 == frame2) bv = reinterpret_cast<const cpx2 *>(s_fb)[item];
+      if (TV && p1 == frame2) bv = reinterpret_cast<const cpx2 *>(s_fb)[li];
       else bv = b[(long)p1 * HB];
       term(*fa, bv, true);
     }
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
       if (frame2 != p1 && frame2 >= p_begin && frame2 < p_end && pr == (frame2 - p_begin) % nr) {
         int fr = wp + frame2;
         fr = fr < nparts ? fr : fr - nparts;
-        term(a[(long)fr * HB], reinterpret_cast<const cpx2 *>(s_fb)[item], true);
+        term(a[(long)fr * HB], reinterpret_cast<const cpx2 *>(s_fb)[li], true);
       }
     }
     cpx2 mine;
@@ -783,7 +795,7 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
     for (int k = 1; k < sparts; k++) sum = cadd(sum, ld_agent(xa + (long)k * N + i));
     return sum;
   };
-  for (int i = tid; i < N / 2; i += 256) {
+  for (int i = tid; i < N / 2; i += WG) {
     if (i == 0) {
       const cpx c0 = xsum(0);
       s_x[0] = mk(c0.x + c0.y, c0.x - c0.y);
@@ -818,6 +830,15 @@ __global__ __launch_bounds__(256) void k_pconv_coop(const float *__restrict__ in
         pass_compute<LOGB, G::LOGE, 8, false>(v, tid, s_tab);
       }
     }
+    if constexpr (LOGB > 12) {
+      __syncthreads();
+      if (tid < T) pass_scatter<LOGB, G::LOGE, 8>(v, tid, [&](int p, cpx val) { s_x[lds_pad(p)] = val; });
+      __syncthreads();
+      if (tid < T) {
+        pass_gather<LOGB, G::LOGE>(v, tid, [&](int p) { return s_x[lds_pad(p)]; });
+        pass_compute<LOGB, G::LOGE, 12, false>(v, tid, s_tab);
+      }
+    }
     if (tid < T) {
       constexpr float inv = 1.0f / (float)N;
       cpx *o = reinterpret_cast<cpx *>(out + (long)ch * N);
@@ -844,6 +865,8 @@ PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di) {
     return e ? atol(e) : 128L;
   }();
   PconvCoop c{-1, 1};
+  // (partitions of 8192 samples were measured on this kernel with 512-lane workgroups: 27 us static, 36 us time-varying
+  // against 29 us on the chain — a workgroup's own 8192-point transforms take 10 us each — so they stay on the chain)
   if (g.logb < 5 || g.logb > 12 || cap_kb <= 0) return c;
   int logs = g.logb - 5;                                  // 32 bins per workgroup
   const int logs_min = g.logb > 9 ? g.logb - 9 : 0;       // at most 256 16-byte items per workgroup (one per lane)
@@ -871,10 +894,10 @@ static hipError_t launch_coop_one(const PconvGeom &g, PconvCoop c, const float *
                                   const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s) {
   const dim3 grid(c.sparts << c.logs, g.channels);
   if (in2)
-    hipLaunchKernelGGL((k_pconv_coop<LOGB, true>), grid, dim3(256), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
+    hipLaunchKernelGGL((k_pconv_coop<LOGB, true>), grid, dim3(LdsGeom<LOGB>::WG), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
                        wp, g.nparts, half, w2f, w2i, xacc, counters, c.logs, c.sparts);
   else
-    hipLaunchKernelGGL((k_pconv_coop<LOGB, false>), grid, dim3(256), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
+    hipLaunchKernelGGL((k_pconv_coop<LOGB, false>), grid, dim3(LdsGeom<LOGB>::WG), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
                        wp, g.nparts, half, w2f, w2i, xacc, counters, c.logs, c.sparts);
   return hipGetLastError();
 }
