@@ -1,13 +1,22 @@
-// dev tool (not product): round-3 experiments on the memory skeleton of the resident n = 65536 kernel.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench2.hip -o gpurun_out/ubench2 && gpurun_out/ubench2 [model|percu|all]
+// dev tool (not product): round-3 experiments on the memory skeleton of the resident n = 65536 kernel and on in-place
+// streams in general.  Results: profiles/ubench2_*_r03.txt; reading: DESIGN.md sections 4 and 4.2.
+//   hipcc -std=c++20 --offload-arch=gfx950 -O3 -fno-slp-vectorize tools/ubench2.hip -o /tmp/ubench2
+//   /tmp/ubench2 [all = model + percu | model3 | model3b | model3c | maps | rev | rev2]
 //
-// model : one 256-lane workgroup per CU (one wave per SIMD), a transform (256 rows x 2 KiB) at a time, in place.
-//         Phase 1 reads 16 column blocks (128-byte row segments), DEPTH blocks in flight, one load per hook point
-//         (16 hooks per block, W v_pk_fma between hooks, one LDS exchange + 2 barriers per block); phase 2 writes 16
-//         column blocks, one store per hook.  Knobs: DEPTH (blocks in flight), LW / SW (bytes per lane of a load /
-//         store: 16 = the half-waves take different rows, a v_permlane32_swap away from the 8-byte layout), W.
-//         Per-phase s_memtime stamps.  Answers: is phase 1 latency-bound (depth), is phase 2 store-issue-bound (width)?
-// percu : what ONE compute unit can read / write per cycle when only K of the 256 CUs are active.
+// model  : one 256-lane workgroup per CU (one wave per SIMD), a transform (256 rows x 2 KiB) at a time, in place.
+//          Phase 1 reads 16 column blocks (128-byte row segments), DEPTH blocks in flight, one load per hook point
+//          (16 hooks per block, W v_pk_fma between hooks, one LDS exchange + 2 barriers per block); phase 2 writes 16
+//          column blocks, one store per hook.  Knobs: DEPTH (blocks in flight), LW / SW (bytes per lane of a load /
+//          store: 16 = the half-waves take different rows, a v_permlane32_swap away from the 8-byte layout), W, each
+//          stream switched off.  Per-phase s_memtime stamps.  Calibrates to the kernel (0.874 vs 0.865-0.885 ms).
+// percu  : what ONE compute unit can read / write when only K of the 256 CUs are active.
+// model3 : the same skeleton in groups of 2 / 4 ADJACENT column blocks whose rows are requested alternately
+//          (256 / 512 contiguous bytes close in time), loads one group ahead, stores one group behind;
+//          model3b: which stream gains, aligned vs straddling pairs, bursts; model3c: all rows of a block needed at
+//          its start (as the real kernel needs them).
+// maps   : other lane -> (column, row) bijections for the loads and stores of `model`.
+// rev(2) : lane order of the accesses of an in-place stream of 64 KiB chunks (ascending, descending on odd rows,
+//          descending, rotated), in place / out of place, non-temporal / plain.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
