@@ -474,6 +474,126 @@ template <int LD, int ST, bool OOP, bool NT> __global__ __launch_bounds__(512) v
   }
 }
 
+// ---------------------------------------------------------------- modelB
+// Another resident decomposition, N = 16 x 4096 instead of 256 x 256: phase 1 = 16-point transforms over the 16 rows of
+// 4096 contiguous elements (no exchange; loads of 2 KiB contiguous per workgroup instruction, rows 32 KiB apart),
+// phase 2 = sixteen 4096-point transforms from the keep matrix (3 passes, 2 exchanges each, NO memory traffic),
+// phase 3 = one more exchange per block (the transposition that makes the stores contiguous) + fully contiguous
+// stores (32 KiB per block).  Same arithmetic as the 256 x 256 form, 48 exchanges instead of 32; but every global
+// access is part of a long contiguous run.  What would its memory skeleton deliver?
+template <int DEPTH, int W, bool XCHG> __global__ __launch_bounds__(256) void k_modelB(char *data, long mats, unsigned long long *dbg, float *sink) {
+  __shared__ f2 sx[16 * 258 + 64];
+  Acc A;
+#pragma unroll
+  for (int i = 0; i < 8; i++) A.a[i] = f2{1.0f + i, 0.5f};
+  f2 z[DEPTH][16];
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) z[d][e] = f2{0.f, 0.f};
+  unsigned long long c1 = 0, c2 = 0, c3 = 0;
+  long m = blockIdx.x;
+  if (m >= mats) return;
+  auto voff = [&]() {
+    int l = threadIdx.x;
+    asm volatile("" : "+v"(l));
+    return l * 8;
+  };
+  auto load_blk = [&](auto zc, const char *x, int j, int vo) {   // block j: rows e = 0..15, 2 KiB at j * 2 KiB of each
+    constexpr int Z = decltype(zc)::value;
+    const __amdgpu_buffer_rsrc_t r = rsrc(x + j * 2048);
+    [&]<int... K>(std::integer_sequence<int, K...>) {
+      ((z[Z][K] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, vo, K * 32768, 2))), ...);
+    }(std::make_integer_sequence<int, 16>());
+  };
+  {
+    const int vo = voff();
+    [&]<int... Z>(std::integer_sequence<int, Z...>) { (load_blk(ic<Z>(), data + m * 524288, Z, vo), ...); }(std::make_integer_sequence<int, DEPTH>());
+  }
+#pragma unroll 1
+  for (; m < mats; m += gridDim.x) {
+    char *x = data + m * 524288;
+    long mn = m + gridDim.x;
+    mn = mn < mats ? mn : m;
+    const char *xn = data + mn * 524288;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    // ---- phase 1: 16 blocks, one 16-point transform + twiddles each, loads DEPTH blocks ahead (the last DEPTH blocks
+    // fetch nothing: the next transform's first blocks are fetched during phase 3)
+    auto p1 = [&](auto zc, int j, bool more) {
+      constexpr int Z = decltype(zc)::value;
+      const int vo = voff();
+      f2 cur[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) cur[e] = z[Z][e];
+      const __amdgpu_buffer_rsrc_t r = rsrc(x + (j + DEPTH) * 2048);
+      [&]<int... K>(std::integer_sequence<int, K...>) {
+        auto hook = [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          busy<W / 2>(A);
+          A.a[k & 7] += cur[k];
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) z[Z][k] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, vo, k * 32768, 2));
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        (hook(ic<K>()), ...);
+      }(std::make_integer_sequence<int, 16>());
+    };
+    constexpr int R1 = 16 / DEPTH;
+#pragma unroll 1
+    for (int rd = 0; rd < R1; rd++)
+      [&]<int... Z>(std::integer_sequence<int, Z...>) { (p1(ic<Z>(), rd * DEPTH + Z, rd + 1 < R1), ...); }(std::make_integer_sequence<int, DEPTH>());
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    c1 += t1 - t0;
+    // ---- phase 2: sixteen 4096-point transforms out of the keep matrix: 3 passes and 2 exchanges each, no memory
+    f2 cur[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) cur[e] = A.a[e & 7];
+#pragma unroll 1
+    for (int k1 = 0; k1 < 16; k1++) {
+#pragma unroll
+      for (int pass = 0; pass < 3; pass++) {
+#pragma unroll
+        for (int h = 0; h < 16; h++) busy<W / 2>(A);
+        if (pass < 2 && XCHG) xchg(cur, sx);
+      }
+    }
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    c2 += t2 - t1;
+    // ---- phase 3: 16 blocks: the transposing exchange, then 16 contiguous stores (2 KiB per instruction, 32 KiB per
+    // block); the last DEPTH blocks also fetch the next transform's first DEPTH blocks
+    auto p3 = [&](auto zc, int blk, bool pre) {
+      constexpr int Z = decltype(zc)::value;
+      const int vo = voff();
+      if (XCHG) xchg(cur, sx);
+      const __amdgpu_buffer_rsrc_t r = rsrc(x + blk * 32768), rn = rsrc(xn + Z * 2048);
+      [&]<int... K>(std::integer_sequence<int, K...>) {
+        auto hook = [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          busy<4>(A);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, cur[k] + A.a[k & 7]), r, vo, k * 2048, 2);
+          if (pre) z[Z][k] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rn, vo, k * 32768, 2));
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        (hook(ic<K>()), ...);
+      }(std::make_integer_sequence<int, 16>());
+    };
+#pragma unroll 1
+    for (int rd = 0; rd < R1; rd++)
+      [&]<int... Z>(std::integer_sequence<int, Z...>) { (p3(ic<Z>(), rd * DEPTH + Z, rd + 1 == R1), ...); }(std::make_integer_sequence<int, DEPTH>());
+    c3 += __builtin_amdgcn_s_memtime() - t2;
+  }
+  if (threadIdx.x == 0) {
+    dbg[3 * blockIdx.x] = c1;
+    dbg[3 * blockIdx.x + 1] = c2;
+    dbg[3 * blockIdx.x + 2] = c3;
+  }
+  f2 s2 = A.a[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++) s2 += A.a[i];
+  if (s2.x == 123.456f) *sink = s2.y;
+}
+
 // ---------------------------------------------------------------- percu
 // K workgroups (one per CU, K <= CUs), each streaming over its own matrices in 128-byte column blocks
 // MODE 1 read only, 2 write only; W16: 16-byte accesses (row-split half-waves)
@@ -792,6 +912,52 @@ int main(int argc, char **argv) {
       std::sort(v.begin(), v.end());
       printf("%-86s %7.3f ms (min %.3f)  %5.2f TB/s   p1 %5.1f  p2 %5.1f\n", sh.name, v[v.size() / 2], v.front(),
              by / v[v.size() / 2] * 1e-9, sh.p1, sh.p2);
+    }
+  }
+
+  if (!strcmp(what, "modelB")) {
+    printf("\n[modelB] resident skeleton of a 16 x 4096 decomposition (contiguous loads, one more exchange per block, contiguous stores);\n"
+           "         kcycles per transform and CU in phase 1 (loads) / 2 (no memory) / 3 (stores)\n");
+    std::vector<unsigned long long> h3(3 * cus);
+    struct Shape {
+      char name[96];
+      std::function<void()> launch;
+      std::vector<float> ms;
+      double p1, p2, p3;
+    };
+    std::vector<Shape> shapes;
+#define MB(DEPTH, W, XCHG)                                                                                                \
+  {                                                                                                                       \
+    Shape s;                                                                                                              \
+    snprintf(s.name, sizeof s.name, "depth %d  W %2d  xchg %d", DEPTH, W, (int)XCHG);                                     \
+    s.launch = [=] { hipLaunchKernelGGL((k_modelB<DEPTH, W, XCHG>), dim3(cus), dim3(256), 0, 0, a, mats, dbg, sink); };    \
+    shapes.push_back(s);                                                                                                  \
+  }
+    MB(2, 22, true) MB(4, 22, true) MB(8, 22, true) MB(4, 16, true) MB(4, 0, false) MB(8, 0, false)
+    Shape ref;
+    snprintf(ref.name, sizeof ref.name, "256 x 256 (model2 depth 2, W 22) for comparison");
+    ref.launch = [=] { hipLaunchKernelGGL((k_model2<2, 22, false, false, true, 0>), dim3(cus), dim3(256), 0, 0, a, mats, dbg, sink); };
+    shapes.push_back(ref);
+    for (int round = 0; round < 4; round++)
+      for (auto &sh : shapes) {
+        sh.ms.push_back(time_launches(6, 30, sh.launch));
+        CK(hipMemcpy(h3.data(), dbg, 3 * cus * 8, hipMemcpyDeviceToHost));
+        double s1 = 0, s2 = 0, s3 = 0;
+        for (int i = 0; i < cus; i++) {
+          s1 += h3[3 * i];
+          s2 += h3[3 * i + 1];
+          s3 += h3[3 * i + 2];
+        }
+        sh.p1 = s1 / mats * 1e-3;
+        sh.p2 = s2 / mats * 1e-3;
+        sh.p3 = s3 / mats * 1e-3;
+      }
+    const double by = 2.0 * (double)mats * 524288;
+    for (auto &sh : shapes) {
+      std::vector<float> v = sh.ms;
+      std::sort(v.begin(), v.end());
+      printf("%-52s %7.3f ms (min %.3f)  %5.2f TB/s   p1 %5.1f  p2 %5.1f  p3 %5.1f\n", sh.name, v[v.size() / 2], v.front(),
+             by / v[v.size() / 2] * 1e-9, sh.p1, sh.p2, sh.p3);
     }
   }
 
