@@ -433,6 +433,25 @@ __device__ __forceinline__ cpx ld_r15(const cpx *p) {
   if (CLFA_NT_LD_R15) return ld_nt(p);
   return *p;
 }
+// Byte offsets (vector part, scalar part) of the four packed bins of slot (u, q) of lane t (rfft15_pos(i, which),
+// i = pair_index<14, 4>(t, u, q)): every one of them is C + j or C - j, j = t + 1024 u, so the lane part is one of TWO
+// VGPRs (t * 8, (1024 - t) * 8) and the rest scalar.  With flat addresses each of the 32 accesses of a lane carried
+// its own 64-bit address pair — hipcc then issued the inverse kernel's loads four at a time, each group behind a
+// full s_waitcnt vmcnt(0): eight exposed memory latencies per transform.  The u = 0 slots carry lane 0's exceptions
+// (pair_index, rfft15_pos) in the vector part.
+struct R15Off {
+  int v, s;
+};
+__device__ __forceinline__ R15Off rfft15_off(const XferBuf &b, int t, int u, int q, int which) {
+  constexpr int M = kM15, NB = 4096, T = 1024;
+  if (u == 0) return R15Off{rfft15_pos(pair_index<14, 4>(t, 0, q), which) * 8, 0};
+  // i = (q < 2 ? +j : -j) + ci;  position = which 0: i, 1: 2M - i, 2: M - i, 3: M + i
+  const bool ineg = q >= 2;
+  const int ci = q == 0 ? 0 : q == 1 ? NB : q == 2 ? 2 * NB : NB;
+  const bool neg = (which == 1 || which == 2) ? !ineg : ineg;                       // sign of j in the position
+  const int c = which == 0 ? ci : which == 1 ? 2 * M - ci : which == 2 ? M - ci : M + ci;   // position = c +- j
+  return neg ? R15Off{b.vd, (c - u * T - T) * 8} : R15Off{b.va, (c + u * T) * 8};
+}
 __device__ __forceinline__ void st_nt16(cpx *p, f4v v) {
   if (CLFA_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(p));
   else *reinterpret_cast<f4v *>(p) = v;
@@ -461,6 +480,7 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
     const LaneTab14 tab{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0, wl1, cmul(wl0, wl1)};
     const cpx g0 = cmul(h0, h0);   // W_32768^tid
     cpx *x = data + b * (long)(2 * kM15);
+    const XferBuf xo{__builtin_amdgcn_make_buffer_rsrc(x, 0, 0x7fffffff, 0x00020000), t * 8, (T - t) * 8};
     cpx va[E], vb[E];
     if constexpr (FWD) {
 #pragma unroll
@@ -495,17 +515,26 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
       });
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {
+        // (flat addresses for the forward kernel's stores: buffer-addressed they were measured 2 % slower)
         rfft15_fwd_slot(t, k / R, k % R, pair_index<LOGN, LOGE>(t, k / R, k % R), ai[k], aj[k], bi[k], bj[k], g0, h0,
                         [&](int pos, cpx v) { st_nt(x + pos, v); });
         __builtin_amdgcn_sched_barrier(0);   // slot by slot: hoisted, the eight slots' twiddles spill
       }
     } else {
       cpx oa[E / 2], pa[E / 2], ob[E / 2], pb[E / 2];
+      cpx raw[2 * E];   // all 32 loads of the lane are in flight before the first slot is computed
 #pragma unroll
-      for (int k = 0; k < E / 2; k++) {   // (left to the scheduler: with the loads fenced off first the prologue spills more)
+      for (int k = 0; k < E / 2; k++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const R15Off o = rfft15_off(xo, t, k / R, k % R, w);
+          raw[4 * k + w] = ld_buf<CLFA_NT_LD_R15 != 0>(xo, o.v, o.s);
+        }
+#pragma unroll
+      for (int k = 0; k < E / 2; k++) {
         const int i = pair_index<LOGN, LOGE>(t, k / R, k % R);
-        rfft15_inv_slot(t, k / R, k % R, i, g0, h0, ld_r15(x + rfft15_pos(i, 0)), ld_r15(x + rfft15_pos(i, 1)),
-                        ld_r15(x + rfft15_pos(i, 2)), ld_r15(x + rfft15_pos(i, 3)), oa[k], pa[k], ob[k], pb[k]);
+        rfft15_inv_slot(t, k / R, k % R, i, g0, h0, raw[4 * k], raw[4 * k + 1], raw[4 * k + 2], raw[4 * k + 3], oa[k], pa[k],
+                        ob[k], pb[k]);
       }
       constexpr int L1 = pass_last_logns(LOGN, LOGE) - LOGE;
 #ifdef CLFA_R15_SERIAL
