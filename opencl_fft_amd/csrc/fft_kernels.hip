@@ -59,7 +59,18 @@ __device__ __forceinline__ void st_nt(cpx *p, cpx v) {
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 // (measured, interleaved A/B against flat addressing: r2c + c2r of size 16384 0.213 -> 0.203-0.208 ms; the complex
 // transforms, which have one ascending stream each way, lose 2 % at n = 8192 and stay as they were)
-template <int LOGN, int MODE> constexpr bool kLdsBufAddr = LdsGeom<LOGN>::FPW == 1 && LOGN >= 12 && MODE != MODE_C2C;
+// (A/B switches: buffer addressing for the complex n = 8192 kernels, per direction.  Measured: inverse 0.780 -> 0.835 ms,
+// forward 0.789 -> 0.827 ms per 2 GiB — both lose, although the inverse instantiation carries a 20-byte spill on flat
+// addresses; they stay off.)
+#ifndef CLFA_BUF_C2C13_INV
+#define CLFA_BUF_C2C13_INV 0
+#endif
+#ifndef CLFA_BUF_C2C13_FWD
+#define CLFA_BUF_C2C13_FWD 0
+#endif
+template <int LOGN, int MODE, bool FWD = true>
+constexpr bool kLdsBufAddr = LdsGeom<LOGN>::FPW == 1 && LOGN >= 12 &&
+                             (MODE != MODE_C2C || (LOGN == 13 && (FWD ? CLFA_BUF_C2C13_FWD : CLFA_BUF_C2C13_INV)));
 struct XferBuf {
   __amdgpu_buffer_rsrc_t r;
   int va;   // t * 8: ascending positions t + c
@@ -120,7 +131,7 @@ template <int LOGN, int LOGE> __device__ __forceinline__ PairOff<LOGN, LOGE> pai
   return o;
 }
 
-template <int LOGN, int MODE>
+template <int LOGN, int MODE, bool FWD = true>
 __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const cpx *x, int t) {
   // No predicates on purpose: callers clamp the transform index instead.  Loads inside
   // exec-masked or even uniform branches make hipcc lose count of them and wait vmcnt(0) at the
@@ -128,9 +139,9 @@ __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const c
   // counted s_waitcnt vmcnt(N) and stay in flight behind the passes.
   using G = LdsGeom<LOGN>;
   constexpr int N = G::N, E = G::E, T = G::T;
-  if constexpr (kLdsBufAddr<LOGN, MODE>) {
+  if constexpr (kLdsBufAddr<LOGN, MODE, FWD>) {
     const XferBuf b = xfer_buf<LOGN>(x, t);
-    constexpr bool NT = MODE == MODE_C2R ? CLFA_NT_LD_C2R : CLFA_NT_LD_R2C;
+    constexpr bool NT = MODE == MODE_C2C ? CLFA_NT_LD != 0 : (MODE == MODE_C2R ? CLFA_NT_LD_C2R : CLFA_NT_LD_R2C);
     if constexpr (MODE == MODE_C2R) {
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   cpx v[E], vn[E];
   {
     const long b = g * FPW + f;
-    lds_fft_load<LOGN, MODE>(v, data + (b < batch ? b : batch - 1) * (long)N, t);
+    lds_fft_load<LOGN, MODE, FWD>(v, data + (b < batch ? b : batch - 1) * (long)N, t);
   }
   for (int i = tid; i < (TWO ? NTAB : N / 2); i += WG) s_tab[i] = tab_g[i];
   cpx *xb = s_x + f * G::PADN;
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       long gn = g + gridDim.x;
       gn = gn < groups ? gn : groups - 1;
       const long bn = gn * FPW + f;
-      lds_fft_load<LOGN, MODE>(vn, data + (bn < batch ? bn : batch - 1) * (long)N, t);
+      lds_fft_load<LOGN, MODE, FWD>(vn, data + (bn < batch ? bn : batch - 1) * (long)N, t);
     }
     if constexpr (MODE == MODE_C2R && PAIRED) {
       // fused reference `iconv` (cl_fft.cpp:192-205) in registers, then the transposed pass chain
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     // loaded the same input in the same instruction as its owner and store bit-identical output.
     (void)active;
     [[maybe_unused]] XferBuf xo{};
-    if constexpr (kLdsBufAddr<LOGN, MODE>) xo = xfer_buf<LOGN>(x, t);
+    if constexpr (kLdsBufAddr<LOGN, MODE, FWD>) xo = xfer_buf<LOGN>(x, t);
     if constexpr (MODE == MODE_R2C && PAIRED) {
       // fused reference `conv` (cl_fft.cpp:178-191): both bins of every pair are in this lane's registers
       pairs_visit<LOGN, G::LOGE>(v, t, [&](int k, int i, cpx ci, cpx cj) {
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
           oi = mk(ci.x + ci.y, ci.x - ci.y);
           oj = cscale(cj, 2.0f);
         }
-        if constexpr (kLdsBufAddr<LOGN, MODE>) {
+        if constexpr (kLdsBufAddr<LOGN, MODE, FWD>) {
           const auto o = pair_off<LOGN, G::LOGE>(xo, t, k / RREM, k % RREM);
 #ifdef CLFA_EXP_SKIP_BOUNDARY   // timing experiment (wrong results): the descending streams without the element that
           // falls into the neighbouring wave's 512-byte block (lane 0 of every wave)
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
           oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
           oj = cj;
         }
-        if constexpr (kLdsBufAddr<LOGN, MODE>) {
+        if constexpr (kLdsBufAddr<LOGN, MODE, FWD>) {
           st_buf(xo, xo.va, T * k * 8, oi);
           if (k == 0) st_buf(xo, t == 0 ? (N / 2) * 8 : (N - t) * 8, 0, oj);
           else st_buf(xo, xo.vd, (N - T * k - T) * 8, oj);
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
           st_nt(x + j, oj);
         }
       }
-    } else if constexpr (kLdsBufAddr<LOGN, MODE>) {
+    } else if constexpr (kLdsBufAddr<LOGN, MODE, FWD>) {
 #pragma unroll
       for (int e = 0; e < E; e++) st_buf(xo, xo.va, T * e * 8, v[e]);
     } else {
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       long gn = g + gridDim.x;
       gn = gn < groups ? gn : groups - 1;
       const long bn = gn * FPW + f;
-      lds_fft_load<LOGN, MODE>(v, data + (bn < batch ? bn : batch - 1) * (long)N, t);
+      lds_fft_load<LOGN, MODE, FWD>(v, data + (bn < batch ? bn : batch - 1) * (long)N, t);
     }
   }
 }
