@@ -162,7 +162,7 @@ class Workload:
             self.step = lambda k: pc.process_device(self.out, self.inp, None, stream.cuda_stream)
             self.workload = ("partitioned convolution, %d channels per GPU, pts=1024, IR 96256 (94 partitions), 48 kHz "
                              "(BASELINE configs[3])" % ch)
-            self.kernel, self.tkey = "k_pconv_fused", "pconv1024x94"
+            self.kernel, self.tkey = pc.kernel_name(), "pconv1024x94"
             self.metric = "channel-samples/s for partitioned convolution (x1e9)"
             self.direction = "one block of 1024 samples per channel per step"
         self.launches_before_timed = 0

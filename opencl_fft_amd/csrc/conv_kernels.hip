@@ -878,11 +878,19 @@ PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di) {
   // (measured, real-time ratio of one time-varying channel: M = 512, L = 2^21: 448 here against 482 on the chain,
   // L = 2^22: 384 / 401; M = 2048, L = 2^21: 1761 / 1804 — every workgroup repeats the forward transform, and
   // the last one adds up all the segments)
-  long room = (di.num_cus / 2) / ((long)g.channels << logs);
+  const long wgs = (long)g.channels << logs;
+  long room = (di.num_cus / 2) / wgs;
   if (room < 1) room = 1;
   if (sparts > g.nparts / 4) sparts = g.nparts / 4;          // segments of at least 4 partitions
   if (sparts < 1) sparts = 1;
-  if (sparts > room) return c;
+  if (sparts > room) {
+    // Many channels: their bin slices alone occupy half the chip or more, every workgroup streams its whole share
+    // (up to 1 MiB) and nothing is cut or added up.  Measured at pts 1024 x 94 partitions, per block: 24 channels
+    // 24.0 (chain) -> 15.5 us, 32: 24.1 -> 16.4, 64: 33.0 -> 24.0, 100: 41.4 -> 32.6, 128: 45.4 -> 40.4, 136: 55.9
+    // -> 50.1; from 137 channels on k_pconv_fused takes over (144: 49.7 against 49.7 here, 256: 68.7 against 73.3).
+    if (2 * wgs < di.num_cus || share > 1024L * 1024) return c;
+    sparts = 1;
+  }
   c.logs = logs;
   c.sparts = (int)sparts;
   return c;

@@ -327,7 +327,9 @@ def test_pconv_push_ir_device_ragged_cvs():
                                                           (32, 5, 1, 12, False), (64, 9, 2, 20, True), (128, 16, 1, 10, False),
                                                           (256, 5, 3, 14, True), (64, 1, 1, 4, False),
                                                           # many channels: fewer, wider bin slices per channel
-                                                          (512, 6, 100, 5, False), (2048, 3, 9, 6, True), (1024, 5, 33, 7, True)])
+                                                          (512, 6, 100, 5, False), (2048, 3, 9, 6, True), (1024, 5, 33, 7, True),
+                                                          # ... streaming their whole share of long rings (no segments)
+                                                          (1024, 94, 24, 3, False), (1024, 94, 100, 2, True)])
 def test_pconv_cooperative_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
     """few channels: one cooperative launch per block (k_pconv_coop: the bins of the multiply-accumulate split over
     the workgroups of a channel, the last workgroup to arrive runs the inverse chain).  Static and time-varying,
