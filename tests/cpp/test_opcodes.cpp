@@ -8,6 +8,8 @@
 #include <cl_fft.h>
 #include <plugin.h>
 
+#include "golden.h"
+
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -168,6 +170,86 @@ int main() {
       for (int k = 0; k < len && k < (int)w.size(); k++) diff += (float)out[k] != w[k];
       CHECK(diff == 0);
       printf("%s k-array of %d values -> %d-point transform: %s\n", real ? "clrfft" : "clfft ", len, np2, diff ? "MISMATCH" : "ok");
+    }
+  }
+  // ---- the same opcodes against the REFERENCE's own vectors (tests/golden/ref: the unmodified reference classes run
+  // on the MI355X through OpenCL): the numbers an opcode hands back to Csound, not only their agreement with the
+  // classes of this repo.  The opcodes add one partition of latency (opcode.cpp:241-249) and nothing else.
+  {
+    const std::vector<float> gir = golden::load_f32("g8_pconv_p1024_n8_ir"), gin = golden::load_f32("g8_pconv_p1024_n8_in"),
+                             gout = golden::load_f32("g8_pconv_p1024_n8_out");
+    CHECK(gir.size() == 8192 && gin.size() == 24 * 1024 && gout.size() == gin.size());
+    if (gir.size() == 8192 && gin.size() == gout.size()) {
+      const int parts = 1024;
+      cs.dbfs = 1.0;
+      std::vector<MYFLT> &tab = cs.tables[3];
+      tab.assign(gir.begin(), gir.end());
+      std::vector<MYFLT> ain(ksmps), aout(ksmps);
+      MYFLT tabno = 3, pr = parts, dev = 0, skip = 0, size = 0;
+      Inst op(cs, "clconv", ksmps, {aout.data()}, {ain.data(), &tabno, &pr, &dev, &skip, &size});
+      CHECK(op.e->init(op.p) == OK);
+      std::vector<float> got;
+      for (size_t n0 = 0; n0 < gin.size(); n0 += ksmps) {
+        for (uint32_t n = 0; n < ksmps; n++) ain[n] = gin[n0 + n];
+        CHECK(op.e->aperf(op.p) == OK);
+        for (uint32_t n = 0; n < ksmps; n++) got.push_back((float)aout[n]);
+      }
+      CHECK(golden::parity(got.data() + parts, gout.data(), got.size() - parts, 2e-6, "clconv opcode vs reference (G8)"));
+    }
+  }
+  {
+    const std::vector<float> g1 = golden::load_f32("g9_tvconv_p256_n5_in1"), g2 = golden::load_f32("g9_tvconv_p256_n5_in2"),
+                             gout = golden::load_f32("g9_tvconv_p256_n5_out");
+    CHECK(g1.size() == 14 * 256 && g2.size() == g1.size() && gout.size() == g1.size());
+    if (g1.size() == 14 * 256 && g2.size() == g1.size() && gout.size() == g1.size()) {
+      const int parts = 256, size = 5 * 256;
+      cs.dbfs = 1.0;
+      std::vector<MYFLT> a1(ksmps), a2(ksmps), aout(ksmps);
+      MYFLT f1 = 1, f2 = 1, pr = parts, sz = size, dev = 0;
+      Inst op(cs, "cltvconv", ksmps, {aout.data()}, {a1.data(), a2.data(), &f1, &f2, &pr, &sz, &dev});
+      CHECK(op.e->init(op.p) == OK);
+      std::vector<float> got;
+      for (size_t n0 = 0; n0 < g1.size(); n0 += ksmps) {
+        for (uint32_t n = 0; n < ksmps; n++) {
+          a1[n] = g1[n0 + n];
+          a2[n] = g2[n0 + n];
+        }
+        CHECK(op.e->aperf(op.p) == OK);
+        for (uint32_t n = 0; n < ksmps; n++) got.push_back((float)aout[n]);
+      }
+      CHECK(golden::parity(got.data() + parts, gout.data(), got.size() - parts, 2e-6, "cltvconv opcode vs reference (G9)"));
+    }
+  }
+  {
+    // clfft: 1024 complex values (LCG 12345, re then im) as a k-rate array of 2048 numbers -> G3
+    const std::vector<float> gf = golden::load_f32("g3_cfft1024_fwd");
+    CHECK(gf.size() == 2048);
+    if (gf.size() == 2048) {
+      golden::Lcg r(12345);
+      csnd::Vector<MYFLT> in, out;
+      in.init(&cs, 2048);
+      for (int k = 0; k < 2048; k++) in[k] = r.sym();
+      MYFLT fwd = 1, dev = 0;
+      Inst op(cs, "clfft", ksmps, {reinterpret_cast<MYFLT *>(&out)}, {reinterpret_cast<MYFLT *>(&in), &fwd, &dev});
+      CHECK(op.e->init(op.p) == OK && op.e->kperf(op.p) == OK);
+      std::vector<float> got(2048);
+      for (int k = 0; k < 2048; k++) got[k] = (float)out[k];
+      CHECK(golden::parity(got.data(), gf.data(), 2048, 1e-6, "clfft opcode vs reference (G3)"));
+    }
+    // clrfft: 2048 real values (LCG 12345) -> G5 (packed spectrum, 1024 bins)
+    const std::vector<float> gr = golden::load_f32("g5_rfft2048_fwd");
+    CHECK(gr.size() == 2048);
+    if (gr.size() == 2048) {
+      golden::Lcg r(12345);
+      csnd::Vector<MYFLT> in, out;
+      in.init(&cs, 2048);
+      for (int k = 0; k < 2048; k++) in[k] = r.sym();
+      MYFLT fwd = 1, dev = 0;
+      Inst op(cs, "clrfft", ksmps, {reinterpret_cast<MYFLT *>(&out)}, {reinterpret_cast<MYFLT *>(&in), &fwd, &dev});
+      CHECK(op.e->init(op.p) == OK && op.e->kperf(op.p) == OK);
+      std::vector<float> got(2048);
+      for (int k = 0; k < 2048; k++) got[k] = (float)out[k];
+      CHECK(golden::parity(got.data(), gr.data(), 2048, 1e-6, "clrfft opcode vs reference (G5)"));
     }
   }
   // ---- a bad device index is an init error, not a crash ----
