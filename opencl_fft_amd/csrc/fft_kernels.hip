@@ -59,18 +59,11 @@ __device__ __forceinline__ void st_nt(cpx *p, cpx v) {
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 // (measured, interleaved A/B against flat addressing: r2c + c2r of size 16384 0.213 -> 0.203-0.208 ms; the complex
 // transforms, which have one ascending stream each way, lose 2 % at n = 8192 and stay as they were)
-// (A/B switches: buffer addressing for the complex n = 8192 kernels, per direction.  Measured: inverse 0.780 -> 0.835 ms,
+// (buffer addressing for the complex n = 8192 kernels was measured per direction as well: inverse 0.780 -> 0.835 ms,
 // forward 0.789 -> 0.827 ms per 2 GiB — both lose, although the inverse instantiation carries a 20-byte spill on flat
-// addresses; they stay off.)
-#ifndef CLFA_BUF_C2C13_INV
-#define CLFA_BUF_C2C13_INV 0
-#endif
-#ifndef CLFA_BUF_C2C13_FWD
-#define CLFA_BUF_C2C13_FWD 0
-#endif
+// addresses)
 template <int LOGN, int MODE, bool FWD = true>
-constexpr bool kLdsBufAddr = LdsGeom<LOGN>::FPW == 1 && LOGN >= 12 &&
-                             (MODE != MODE_C2C || (LOGN == 13 && (FWD ? CLFA_BUF_C2C13_FWD : CLFA_BUF_C2C13_INV)));
+constexpr bool kLdsBufAddr = LdsGeom<LOGN>::FPW == 1 && LOGN >= 12 && MODE != MODE_C2C;
 struct XferBuf {
   __amdgpu_buffer_rsrc_t r;
   int va;   // t * 8: ascending positions t + c
@@ -362,15 +355,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
         }
         if constexpr (kLdsBufAddr<LOGN, MODE, FWD>) {
           const auto o = pair_off<LOGN, G::LOGE>(xo, t, k / RREM, k % RREM);
-#ifdef CLFA_EXP_SKIP_BOUNDARY   // timing experiment (wrong results): the descending streams without the element that
-          // falls into the neighbouring wave's 512-byte block (lane 0 of every wave)
-          const bool desc_i = (k % RREM) >= RREM / 2;
-          if (!desc_i || (t & 63) != 0) st_buf(xo, o.vi, o.si, oi);
-          if (desc_i || (t & 63) != 0) st_buf(xo, o.vj, o.sj, oj);
-#else
           st_buf(xo, o.vi, o.si, oi);
           st_buf(xo, o.vj, o.sj, oj);
-#endif
         } else {
           st_nt(x + i, oi);
           st_nt(x + j, oj);
@@ -500,13 +486,8 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
         va[e] = mk(q.x, q.y);
         vb[e] = mk(q.z, q.w);
       }
-#ifdef CLFA_R15_SERIAL   // A/B switch: the two chains one after the other (round 2)
-      wg_passes<LOGN, LOGE, 0, true, true>(va, t, tab, xb);
-      wg_passes<LOGN, LOGE, 0, true, true>(vb, t, tab, xb);
-#else
       pass_compute<LOGN, LOGE, 0, true>(va, t, tab);
       wg_passes_pair<LOGN, LOGE, 0, true>(va, vb, t, tab, xb);   // staggered: one chain's LDS transfers under the other's passes
-#endif
       if constexpr (SCALE) {
         constexpr float inv = 1.0f / (float)(2 * kM15);
 #pragma unroll
@@ -548,18 +529,6 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
                         ob[k], pb[k]);
       }
       constexpr int L1 = pass_last_logns(LOGN, LOGE) - LOGE;
-#ifdef CLFA_R15_SERIAL
-      pass_first_paired<LOGN, LOGE, false>(va, t, oa, pa, tab);
-      __syncthreads();
-      pass_first_paired_scatter<LOGN, LOGE>(va, t, xb);
-      __syncthreads();
-      wg_passes_dif_after<LOGN, LOGE, L1, false>(va, t, tab, xb);
-      pass_first_paired<LOGN, LOGE, false>(vb, t, ob, pb, tab);
-      __syncthreads();
-      pass_first_paired_scatter<LOGN, LOGE>(vb, t, xb);
-      __syncthreads();
-      wg_passes_dif_after<LOGN, LOGE, L1, false>(vb, t, tab, xb);
-#else
       // staggered (fft_wg.hpp, wg_passes_dif_pair): one chain's scatter drains under the other's butterflies
       pass_first_paired<LOGN, LOGE, false>(va, t, oa, pa, tab);
       __syncthreads();
@@ -573,7 +542,6 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
       __syncthreads();
       dif_gather_padded<LOGN, LOGE, L1>(vb, t, xb);
       wg_passes_dif_pair<LOGN, LOGE, L1, false>(va, vb, t, tab, xb);
-#endif
 #pragma unroll
       for (int e = 0; e < E; e++) st_nt16(x + 2 * (t + T * e), f4v{va[e].x, va[e].y, vb[e].x, vb[e].y});
     }
