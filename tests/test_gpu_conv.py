@@ -377,3 +377,41 @@ def test_pconv_cooperative_kernel_device_stream_of_blocks():
     xs = x.cpu().numpy()
     want = np.stack([o.convolution(xs[b, 0]) for b in range(blocks)])
     assert_parity(y[:, 0].cpu().numpy(), want, tol=CTOL, what="300 blocks back to back")
+
+
+def test_pconv_cooperative_handoff_under_load():
+    """The hand-over of the accumulator slices between workgroups (agent-scope stores, arrival counter, the last
+    workgroup reads) under UNEVEN load: the same 200 blocks once on an idle GPU and once while another stream keeps the
+    chip busy with large transforms, so that the cooperative block's workgroups start at different times and share
+    their CUs.  The summation order is fixed, so the two runs must agree bit for bit in every output word."""
+    import torch
+    blocks = 200
+    for pts, nparts, channels, tv in ((512, 128, 1, False), (1024, 94, 3, True), (256, 600, 1, False)):
+        g = torch.Generator(device="cuda").manual_seed(pts + nparts)
+        ir = (torch.rand((channels, pts * nparts), generator=g, device="cuda") - 0.5) / (pts * nparts) ** 0.5
+        x1 = torch.rand((blocks, channels, pts), generator=g, device="cuda") * 2 - 1
+        x2 = (torch.rand((blocks, channels, pts), generator=g, device="cuda") - 0.5) * 0.05
+        big = torch.rand((512, 65536, 2), device="cuda") * 2 - 1
+        f, i = fa.Clcfft(0, 65536, True), fa.Clcfft(0, 65536, False)
+        outs = []
+        for loaded in (False, True):
+            p = fa.Clpconv(0, pts * nparts, pts, channels=channels)
+            assert p.kernel_name() == "k_pconv_coop"
+            if not tv:
+                assert p.push_ir_device(ir) == 0
+            y = torch.empty((blocks, channels, pts), device="cuda")
+            torch.cuda.synchronize()
+            sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+            for b in range(blocks):
+                if loaded and b % 4 == 0:      # ~0.1 ms of transforms on every CU, overlapping the next blocks
+                    assert (f if (b // 4) % 2 == 0 else i).exec_device(big, 512, sb.cuda_stream) == 0
+                assert p.process_device(y[b], x1[b], x2[b] if tv else None, sa.cuda_stream) == 0
+            torch.cuda.synchronize()
+            outs.append(y)
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (pts, nparts, channels, tv)
+        o = oracle.Pconv(pts * nparts, pts)
+        if not tv:
+            o.push_ir(ir[0].cpu().numpy())
+        xs1, xs2 = x1[:, 0].cpu().numpy(), x2[:, 0].cpu().numpy()
+        want = np.stack([o.convolution(xs1[b], xs2[b] if tv else None) for b in range(12)])
+        assert_parity(outs[1][:12, 0].cpu().numpy(), want, tol=CTOL, what="first blocks vs oracle")
