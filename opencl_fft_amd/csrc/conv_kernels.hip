@@ -612,6 +612,54 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
   for (int i = tid; i < N / 2; i += WG) s_tab[i] = tab_g[i];
   __syncthreads();
 
+  // ---- this workgroup's part of the multiply-accumulate: slice = N >> logs bins = IW 16-byte items; lane = item li of
+  // partition row pr; rows walk p = p_begin + pr, + NR, ...  The first loads of the walk (and the ring operands of the
+  // new frames' terms) are issued HERE, before the forward transforms: they need nothing from them, and their memory
+  // latency then runs under 1-2 us of butterflies instead of after them.
+  const int iw = HB >> logs, nr = WG / iw;
+  const int li = tid % iw, pr = tid / iw;
+  const int item = sl * iw + li;                       // 16-byte item (bins 2 item, 2 item + 1) of the frame
+  const cpx2 *ra = reinterpret_cast<const cpx2 *>(ringA + (long)ch * nparts * N) + item;
+  const cpx2 *rb = reinterpret_cast<const cpx2 *>(ringB + (long)ch * nparts * N) + item;
+  const int p1 = nparts - 1;                           // (wp + p1) % nparts == frame1: wp = frame1 + 1
+  const int chunk = (nparts + sparts - 1) / sparts;    // this workgroup's partitions [p_begin, p_end)
+  const int p_begin = ps * chunk, p_end = p_begin + chunk < nparts ? p_begin + chunk : nparts;
+  constexpr int UNR = 4;
+  cpx2 av0[UNR], bv0[UNR];
+  bool live0[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; u++) {   // (clamped, not predicated: straight-line loads)
+    const int pp = p_begin + pr + u * nr;
+    const bool ok = pp < p_end;
+    const int pc = ok ? pp : p_end - 1;
+    int fr = wp + pc;
+    fr = fr < nparts ? fr : fr - nparts;
+    av0[u] = ld_stream(ra + (long)fr * HB);
+    bv0[u] = ld_stream(rb + (long)pc * HB);
+    live0[u] = ok && pc != p1 && !(TV && pc == frame2);
+  }
+  const cpx2 b_p1 = rb[(long)p1 * HB];                 // ring operand of the new A frame's term
+  int fr2 = wp + (TV ? frame2 : 0);
+  fr2 = fr2 < nparts ? fr2 : fr2 - nparts;
+  const cpx2 a_f2 = ra[(long)fr2 * HB];                // ... of the new B frame's term (time-varying blocks)
+  // ... and so are the pack / unpack twiddles of the lane's bins and the overlap-add tail: every global load that does
+  // not depend on this launch's results leaves at the top of the kernel — a block is a chain of dependent steps of a
+  // microsecond each, and every load left in the middle of it is one more
+  constexpr int NI = (N / 2 + WG - 1) / WG;
+  cpx w2f_r[NI], w2i_r[NI];
+#pragma unroll
+  for (int q = 0; q < NI; q++) {
+    const int i = tid + q * WG;
+    w2f_r[q] = w2f_g[i < N / 2 ? i : 0];
+    w2i_r[q] = w2i_g[i < N / 2 ? i : 0];
+  }
+  cpx tail_r[E / 2];
+  {
+    const cpx *tl = reinterpret_cast<const cpx *>(tail + (long)ch * N);
+#pragma unroll
+    for (int e = 0; e < E / 2; e++) tail_r[e] = tl[(tid < T ? tid : 0) + T * e];
+  }
+
   // ---- forward chain(s) in every workgroup: reference reorder + fft + r2c (cl_conv.cpp:399-419 / 465-513) ----
   // Time-varying blocks transform both inputs AT ONCE where the lanes allow it (2 T <= 256): lanes [0, T) take in1,
   // lanes [T, 2 T) in2, each group with its own exchange buffer — one pass chain's worth of barriers, not two.
@@ -669,11 +717,14 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
   const int bw = N >> logs, b0 = sl * bw;   // this workgroup's bins [b0, b0 + bw)
   auto pack = [&](const cpx *sx, cpx *ring, int frame, cpx *sf) {
     cpx *x = ring + ((long)ch * nparts + frame) * N;
-    for (int i = tid; i < N / 2; i += WG) {
+#pragma unroll
+    for (int q = 0; q < NI; q++) {
+      const int i = tid + q * WG;
+      if (i >= N / 2) break;
       const int j = i == 0 ? N / 2 : N - i;
       const cpx ci = sx[lds_pad(i)], cj = sx[lds_pad(j)];
       cpx oi, oj;
-      r2c_pair(ci, cj, w2f_g[i], oi, oj);
+      r2c_pair(ci, cj, w2f_r[q], oi, oj);
       if (i == 0) {
         oi = mk((ci.x + ci.y) * .5f, (ci.x - ci.y) * .5f);
         oj = cj;
@@ -703,13 +754,8 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
   }
 
   // ---- MAC over all partitions for this workgroup's slice of the bins (reference convol, cl_conv_kernels.h:102-118)
-  // slice = N >> logs bins = IW 16-byte items; lane = item li of partition row pr; rows walk p = pr, pr + NR, ...
   {
-    const int iw = HB >> logs, nr = WG / iw;
-    const int li = tid % iw, pr = tid / iw;
-    const int item = sl * iw + li;                       // 16-byte item (bins 2 item, 2 item + 1) of the frame
-    const cpx2 *a = reinterpret_cast<const cpx2 *>(ringA + (long)ch * nparts * N) + item;
-    const cpx2 *b = reinterpret_cast<const cpx2 *>(ringB + (long)ch * nparts * N) + item;
+    const cpx2 *a = ra, *b = rb;
     const bool dc = item == 0;                           // packed DC / Nyquist bin: (re*re, im*im)
     cpx s0 = mk(0.f, 0.f), s1 = mk(0.f, 0.f);
     auto term = [&](const cpx2 &av, const cpx2 &bv, bool live) {
@@ -721,11 +767,9 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
     };
     // the frames written by THIS launch (frame1 of A; frame2 of B) are taken from LDS below: in the loop their
     // (stale) ring contents are read like any other frame and dropped by a select — no branch in the stream
-    const int p1 = nparts - 1;                           // (wp + p1) % nparts == frame1: wp = frame1 + 1
-    const int chunk = (nparts + sparts - 1) / sparts;    // this workgroup's partitions [p_begin, p_end)
-    const int p_begin = ps * chunk, p_end = p_begin + chunk < nparts ? p_begin + chunk : nparts;
-    constexpr int UNR = 4;
-    int p = p_begin + pr;
+#pragma unroll
+    for (int u = 0; u < UNR; u++) term(av0[u], bv0[u], live0[u]);   // the batch fetched before the transforms
+    int p = p_begin + pr + UNR * nr;
     for (; p + (UNR - 1) * nr < p_end; p += UNR * nr) {
       cpx2 av[UNR], bv[UNR];
       bool live[UNR];
@@ -751,14 +795,12 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
     if (p1 >= p_begin && p1 < p_end && pr == (p1 - p_begin) % nr) {
       cpx2 bv;
       if (TV && p1 == frame2) bv = reinterpret_cast<const cpx2 *>(s_fb)[li];
-      else bv = b[(long)p1 * HB];
+      else bv = b_p1;
       term(*fa, bv, true);
     }
     if constexpr (TV) {
       if (frame2 != p1 && frame2 >= p_begin && frame2 < p_end && pr == (frame2 - p_begin) % nr) {
-        int fr = wp + frame2;
-        fr = fr < nparts ? fr : fr - nparts;
-        term(a[(long)fr * HB], reinterpret_cast<const cpx2 *>(s_fb)[li], true);
+        term(a_f2, reinterpret_cast<const cpx2 *>(s_fb)[li], true);
       }
     }
     cpx2 mine;
@@ -795,14 +837,17 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
     for (int k = 1; k < sparts; k++) sum = cadd(sum, ld_agent(xa + (long)k * N + i));
     return sum;
   };
-  for (int i = tid; i < N / 2; i += WG) {
+#pragma unroll
+  for (int q = 0; q < NI; q++) {
+    const int i = tid + q * WG;
+    if (i >= N / 2) break;
     if (i == 0) {
       const cpx c0 = xsum(0);
       s_x[0] = mk(c0.x + c0.y, c0.x - c0.y);
       s_x[lds_pad(N / 2)] = xsum(N / 2);
     } else {
       cpx oi, oj;
-      c2r_pair(xsum(i), xsum(N - i), w2i_g[i], oi, oj);
+      c2r_pair(xsum(i), xsum(N - i), w2i_r[q], oi, oj);
       s_x[lds_pad(i)] = oi;
       s_x[lds_pad(N - i)] = oj;
     }
@@ -846,7 +891,7 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
 #pragma unroll
       for (int e = 0; e < E / 2; e++) {
         const int p = tid + T * e;
-        const cpx old = tl[p];
+        const cpx old = tail_r[e];
         o[p] = mk((v[e].x + old.x) * inv, (v[e].y + old.y) * inv);
         tl[p] = v[e + E / 2];
       }
