@@ -27,6 +27,8 @@ class Cldconv {
   int push_ir(float *ir);
   int convolution(float *output, float *input);
   int convolution(float *out, float *in1, float *in2);
+  /** device-resident extension (in2 may be NULL; out must not be an input) */
+  int convolution_device(void *out, const void *in1, const void *in2, void *stream = 0);
   int get_cl_err() { return cl_err; }
 };
 }  // namespace cl_conv

@@ -156,6 +156,9 @@ CLFA_API int clfa_dconv_get_error(const clfa_dconv *dc);     /* cl_dconv.h:65 */
 CLFA_API int clfa_dconv_push_ir(clfa_dconv *dc, const float *ir);                 /* cl_dconv.cpp:150-153 */
 CLFA_API int clfa_dconv_convolution(clfa_dconv *dc, float *out, const float *in); /* cl_dconv.cpp:109-132 */
 CLFA_API int clfa_dconv_convolution_tv(clfa_dconv *dc, float *out, const float *in1, const float *in2); /* :134-148 */
+/* device-resident variant of both (in2 may be NULL): vsize floats each, asynchronous on `stream`, one launch per
+ * block; out must not be in1 or in2 */
+CLFA_API int clfa_dconv_process_dev(clfa_dconv *dc, void *out, const void *in1, const void *in2, void *stream);
 
 #ifdef __cplusplus
 }

@@ -322,3 +322,13 @@ class Cldconv:
         if b.size != self.vsize:
             return CL_INVALID_VALUE
         return lib().clfa_dconv_convolution_tv(self._h, out.ctypes.data, a.ctypes.data, b.ctypes.data)
+
+    def process_device(self, out, in1, in2=None, stream=None):
+        """device-resident block (extension): vsize float32 each, asynchronous on `stream`; out must not be an input"""
+        for t in (out, in1) + ((in2,) if in2 is not None else ()):
+            if hasattr(t, "numel") and (t.numel() != self.vsize or not t.is_contiguous() or str(t.dtype) != "torch.float32"):
+                return CL_INVALID_VALUE
+        po, stream = _ptr_stream(out, stream)
+        p1, _ = _ptr_stream(in1, stream)
+        p2 = _ptr_stream(in2, stream)[0] if in2 is not None else None
+        return lib().clfa_dconv_process_dev(self._h, po, p1, p2, stream)

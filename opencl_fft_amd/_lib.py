@@ -52,6 +52,7 @@ SYMBOLS = [
     ("clfa_dconv_push_ir", C.c_int, [_vp, _vp]),
     ("clfa_dconv_convolution", C.c_int, [_vp, _vp, _vp]),
     ("clfa_dconv_convolution_tv", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("clfa_dconv_process_dev", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
 ]
 
 _LIB = None

@@ -82,4 +82,7 @@ int Cldconv::convolution(float *out, float *in1, float *in2) {
   if (cl_err) err(cl_error_string(cl_err), userData);
   return cl_err;
 }
+int Cldconv::convolution_device(void *out, const void *in1, const void *in2, void *stream) {
+  return cl_err = clfa_dconv_process_dev(dc, out, in1, in2, stream);
+}
 }  // namespace cl_conv

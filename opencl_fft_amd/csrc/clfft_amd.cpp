@@ -300,6 +300,9 @@ struct clfa_dconv {
   int err = 0;
   hipStream_t stream = nullptr;
   DevBuf del, coefs, out;
+  DevBuf in1, in2;     // staging of the host entry points' input blocks
+  DevBuf part, cnt;    // partial sums per tap chunk and their arrival counter (plan.G > 1)
+  DconvPlan plan{64, 1, 1};
   StreamOrder order;
 };
 
@@ -1023,12 +1026,16 @@ int clfa_dconv_create(clfa_dconv **dc, int device, int irsize, int vsize) {
     if (e) return e;
     ENTER_DEVICE(device);
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    const size_t ring = sizeof(float) * ((size_t)irsize + vsize);
-    if ((e = d->del.ensure(ring)) || (e = d->coefs.ensure(ring)) || (e = d->out.ensure(sizeof(float) * vsize)))
+    const size_t ring = sizeof(float) * ((size_t)irsize + vsize), blk = sizeof(float) * (size_t)vsize;
+    d->plan = dconv_plan(irsize, vsize);
+    if ((e = d->del.ensure(ring)) || (e = d->coefs.ensure(ring)) || (e = d->out.ensure(blk)) || (e = d->in1.ensure(blk)) ||
+        (e = d->in2.ensure(blk)) || (e = d->part.ensure(blk * d->plan.G)) ||
+        (e = d->cnt.ensure(sizeof(unsigned) * d->plan.VB)))
       return e;
     // the reference leaves these uninitialised (cl_dconv.cpp:87-91); zero is the intent
     HIP_TRY(hipMemsetAsync(d->del.p, 0, ring, d->stream));
     HIP_TRY(hipMemsetAsync(d->coefs.p, 0, ring, d->stream));
+    HIP_TRY(hipMemsetAsync(d->cnt.p, 0, sizeof(unsigned) * d->plan.VB, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     return CLFA_SUCCESS;
   };
@@ -1047,6 +1054,10 @@ void clfa_dconv_destroy(clfa_dconv *d) {
   d->del.release();
   d->coefs.release();
   d->out.release();
+  d->in1.release();
+  d->in2.release();
+  d->part.release();
+  d->cnt.release();
   delete d;
 }
 
@@ -1057,45 +1068,54 @@ int clfa_dconv_push_ir(clfa_dconv *d, const float *ir) {
   if (d->err) return d->err;
   if (!ir) return CLFA_INVALID_VALUE;
   ENTER_DEVICE(d->di.device);
+  HIP_TRY(d->order.use(d->stream));
   HIP_TRY(hipMemcpyAsync(d->coefs.p, ir, sizeof(float) * d->irsize, hipMemcpyHostToDevice, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   return CLFA_SUCCESS;
 }
 
-// ring write of vsize floats at wp with wrap-around (intent of cl_dconv.cpp:112-122)
-static int ring_write(clfa_dconv *d, DevBuf &ring, const float *src) {
-  const int end = d->irsize + d->vsize;
-  int first = end - d->wp < d->vsize ? end - d->wp : d->vsize;
-  HIP_TRY(hipMemcpyAsync((float *)ring.p + d->wp, src, sizeof(float) * first, hipMemcpyHostToDevice, d->stream));
-  if (first < d->vsize)
-    HIP_TRY(hipMemcpyAsync(ring.p, src + first, sizeof(float) * (d->vsize - first), hipMemcpyHostToDevice,
-                           d->stream));
+// one block on stream s, everything device-resident: ring write at wp with wrap-around (intent of cl_dconv.cpp:112-122;
+// the two-input form writes in2 into the coefficient ring at the same point, :134-147), wp advanced (:124), vsize
+// outputs — all in ONE launch (conv_kernels.hip, k_dconv_block)
+static int dconv_block(clfa_dconv *d, float *out, const float *in1, const float *in2, hipStream_t s) {
+  const int wp = d->wp;
+  d->wp = (d->wp + d->vsize) % (d->irsize + d->vsize);
+  HIP_TRY(launch_dconv_block(d->plan, out, in1, in2, (float *)d->del.p, (float *)d->coefs.p, (float *)d->part.p,
+                             (unsigned *)d->cnt.p, d->irsize, d->vsize, wp, s));
   return CLFA_SUCCESS;
 }
 
-int clfa_dconv_convolution(clfa_dconv *d, float *out, const float *in) {
+static int dconv_host(clfa_dconv *d, float *out, const float *in1, const float *in2) {
   if (!d) return CLFA_INVALID_VALUE;
   if (d->err) return d->err;
-  if (!out || !in) return CLFA_INVALID_VALUE;
+  if (!out || !in1) return CLFA_INVALID_VALUE;
   ENTER_DEVICE(d->di.device);
-  int e = ring_write(d, d->del, in);
+  HIP_TRY(d->order.use(d->stream));
+  const size_t blk = sizeof(float) * (size_t)d->vsize;
+  HIP_TRY(hipMemcpyAsync(d->in1.p, in1, blk, hipMemcpyHostToDevice, d->stream));
+  if (in2) HIP_TRY(hipMemcpyAsync(d->in2.p, in2, blk, hipMemcpyHostToDevice, d->stream));
+  int e = dconv_block(d, (float *)d->out.p, (const float *)d->in1.p, in2 ? (const float *)d->in2.p : nullptr, d->stream);
   if (e) return e;
-  d->wp = (d->wp + d->vsize) % (d->irsize + d->vsize);   // cl_dconv.cpp:124
-  HIP_TRY(launch_dconv((float *)d->out.p, (const float *)d->del.p, (const float *)d->coefs.p, d->irsize,
-                       d->vsize, d->wp, d->stream));
-  HIP_TRY(hipMemcpyAsync(out, d->out.p, sizeof(float) * d->vsize, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(out, d->out.p, blk, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   return CLFA_SUCCESS;
 }
 
+int clfa_dconv_convolution(clfa_dconv *d, float *out, const float *in) { return dconv_host(d, out, in, nullptr); }
+
 int clfa_dconv_convolution_tv(clfa_dconv *d, float *out, const float *in1, const float *in2) {
+  if (d && !d->err && !in2) return CLFA_INVALID_VALUE;
+  return dconv_host(d, out, in1, in2);
+}
+
+int clfa_dconv_process_dev(clfa_dconv *d, void *out, const void *in1, const void *in2, void *stream) {
   if (!d) return CLFA_INVALID_VALUE;
   if (d->err) return d->err;
-  if (!out || !in1 || !in2) return CLFA_INVALID_VALUE;
+  if (!out || !in1 || out == in1 || out == in2) return CLFA_INVALID_VALUE;
   ENTER_DEVICE(d->di.device);
-  int e = ring_write(d, d->coefs, in2);   // cl_dconv.cpp:134-147
-  if (e) return e;
-  return clfa_dconv_convolution(d, out, in1);
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(d->order.use(s));
+  return dconv_block(d, (float *)out, (const float *)in1, (const float *)in2, s);
 }
 
 }  // extern "C"

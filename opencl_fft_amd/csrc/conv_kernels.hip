@@ -1008,30 +1008,165 @@ hipError_t launch_pconv_olap(const float *work, float *tail, float *out, int bin
 }
 
 // ---------------------------------------------------------------------------------
-// direct convolution (reference convol, cl_dconv.cpp:32-43): one workgroup per
-// output sample, lanes stride the taps, tree reduction instead of CAS atomics
+// direct convolution (reference convol, cl_dconv.cpp:32-43; host side cl_dconv.cpp:109-148): ONE launch per block.
+// The reference runs irsize x vsize work items that each add one product to out[n] with CAS atomics.  Here the work is
+// a grid of (tap chunks) x (output blocks): workgroup (g, y) forms the partial sums of its tiles of 64 outputs over
+// its chunk of C taps from LDS copies of the chunk's coefficients and of the delay-ring window they meet (every ring
+// sample is read from memory once per workgroup and tile, not once per output), four lane rows walking a quarter of
+// the chunk each.  The block's new samples are taken straight from the input (workgroup (0, 0) also files them in the
+// ring — and, for the two-input form, in the coefficient ring — for the blocks to come), so no launch has to precede
+// this one.  With more than one chunk the partial sums of an output block go to whichever of its workgroups arrives
+// LAST at the block's counter (same hand-over as k_pconv_coop: agent-scope stores, s_waitcnt vmcnt(0), barrier, one
+// atomic add; nothing spins), which adds them in a fixed order: the result does not depend on the arrival order.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dconv(float *__restrict__ out, const float *__restrict__ del,
-                                               const float *__restrict__ coefs, int irsize, int vsize, int rp) {
-  __shared__ float s_part[4];
-  const int n = blockIdx.x;
-  const int end = irsize + vsize;
-  float acc = 0.f;
-  for (int h = threadIdx.x; h < irsize; h += 256) {
-    int r = rp + n + h;
-    r = r < end ? r : r % end;
-    acc += del[r] * coefs[irsize - 1 - h];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) out[n] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+constexpr int kDconvNT = 64;        // outputs per tile
+constexpr int kDconvMaxC = 4096;    // taps per workgroup at most
+constexpr int kDconvMaxVB = 512;    // output blocks (= counters) at most
+
+DconvPlan dconv_plan(int irsize, int vsize) {
+  // about 64 K products per workgroup (a microsecond), at most ~512 workgroups; outputs first, then taps
+  const long work = (long)irsize * vsize;
+  long want = work >> 16;
+  want = want < 1 ? 1 : want > 512 ? 512 : want;
+  const int tiles = (vsize + kDconvNT - 1) / kDconvNT;
+  DconvPlan pl;
+  pl.VB = (int)(tiles < want ? tiles : want);
+  if (pl.VB > kDconvMaxVB) pl.VB = kDconvMaxVB;
+  const long gwant = (want + pl.VB - 1) / pl.VB;
+  int c = (int)((irsize + gwant - 1) / gwant);
+  c = (c + 63) / 64 * 64;
+  pl.C = c < 64 ? 64 : c > kDconvMaxC ? kDconvMaxC : c;
+  pl.G = (irsize + pl.C - 1) / pl.C;
+  return pl;
 }
 
-hipError_t launch_dconv(float *out, const float *del, const float *coefs, int irsize, int vsize, int rp,
-                        hipStream_t s) {
-  hipLaunchKernelGGL(k_dconv, dim3(vsize), dim3(256), 0, s, out, del, coefs, irsize, vsize, rp);
+__device__ __forceinline__ void st_agent_f(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent_f(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_dconv_block(float *__restrict__ out, const float *__restrict__ in1,
+                                                     const float *__restrict__ in2, float *__restrict__ del,
+                                                     float *__restrict__ coefs, float *__restrict__ part,
+                                                     unsigned *__restrict__ counters, int irsize, int vsize, int wp, int C) {
+  __shared__ float s_k[kDconvMaxC];
+  __shared__ float s_d[kDconvMaxC + kDconvNT];
+  __shared__ float s_red[256];
+  __shared__ bool s_last;
+  const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x, y = blockIdx.y, VB = gridDim.y;
+  const int end = irsize + vsize;
+  const int rp = (wp + vsize) % end;   // the read point is the write point AFTER this block (cl_dconv.cpp:124)
+  const int h0 = g * C;
+  const int taps = irsize - h0 < C ? irsize - h0 : C;
+  // the rings as they stand once this block's samples are in (cl_dconv.cpp:112-122, 134-147)
+  auto fresh = [&](int r) {   // position of ring index r inside the block being written, or >= vsize
+    const int off = r - wp;
+    return off < 0 ? off + end : off;
+  };
+  // (staging loops: eight independent loads per lane in flight, indices clamped instead of branched around — one at a
+  // time they cost a memory round trip each)
+  for (int jb = tid; jb < taps; jb += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = jb + 256 * u < taps ? jb + 256 * u : taps - 1;
+      const int q = irsize - 1 - (h0 + j);
+      const int off = fresh(q);
+      const float *src = (in2 != nullptr && off < vsize) ? in2 + off : coefs + q;
+      v[u] = *src;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (jb + 256 * u < taps) s_k[jb + 256 * u] = v[u];
+  }
+  const int n = tid & (kDconvNT - 1), row = tid / kDconvNT;   // (row is wave-uniform: its coefficient reads broadcast)
+  const int per = (taps + 3) / 4;
+  const int j0 = row * per, j1 = j0 + per < taps ? j0 + per : taps;
+  for (int n0 = y * kDconvNT; n0 < vsize; n0 += VB * kDconvNT) {
+    __syncthreads();   // the previous tile's readers are done (first tile: s_k is complete)
+    const int span = taps + kDconvNT - 1;
+    const int base = (int)(((long)rp + n0 + h0) % end);
+    for (int jb = tid; jb < span; jb += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = jb + 256 * u < span ? jb + 256 * u : span - 1;
+        int r = base + j;
+        if (r >= end) {
+          r -= end;
+          if (r >= end) r %= end;   // (a ring shorter than the tile's window)
+        }
+        const int off = fresh(r);
+        const float *src = off < vsize ? in1 + off : del + r;
+        v[u] = *src;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (jb + 256 * u < span) s_d[jb + 256 * u] = v[u];
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll 16   // (sixteen LDS reads in flight; the sum stays in ascending tap order)
+    for (int j = j0; j < j1; j++) acc += s_d[n + j] * s_k[j];
+    s_red[tid] = acc;
+    __syncthreads();
+    if (row == 0 && n0 + n < vsize) {
+      const float sum = (s_red[n] + s_red[kDconvNT + n]) + (s_red[2 * kDconvNT + n] + s_red[3 * kDconvNT + n]);
+      if (G == 1) out[n0 + n] = sum;
+      else st_agent_f(part + (long)g * vsize + n0 + n, sum);
+    }
+  }
+  if (g == 0 && y == 0) {   // file the block: nobody reads these ring positions in this launch (everybody takes them from the input)
+    for (int i = tid; i < vsize; i += 256) {
+      const int r = (wp + i) % end;
+      del[r] = in1[i];
+      if (in2 != nullptr) coefs[r] = in2[i];
+    }
+  }
+  if (G == 1) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(counters + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == (unsigned)(G - 1);
+    if (s_last) __hip_atomic_store(counters + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // the output block's partial sums: lane row r adds the chunks of its quarter in ascending order (eight loads in
+  // flight at a time: one after the other they cost a cache round trip each), the quarters meet in LDS in fixed order
+  const int gq = (G + 3) / 4;
+  const int k0 = row * gq, k1 = k0 + gq < G ? k0 + gq : G;
+  for (int n0 = y * kDconvNT; n0 < vsize; n0 += VB * kDconvNT) {
+    float sum = 0.f;
+    if (n0 + n < vsize) {
+      const float *pp = part + n0 + n;
+      int k = k0;
+      for (; k + 8 <= k1; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = ld_agent_f(pp + (long)(k + u) * vsize);
+#pragma unroll
+        for (int u = 0; u < 8; u++) sum += v[u];
+      }
+      for (; k < k1; k++) sum += ld_agent_f(pp + (long)k * vsize);
+    }
+    s_red[tid] = sum;
+    __syncthreads();
+    if (row == 0 && n0 + n < vsize)
+      out[n0 + n] = (s_red[n] + s_red[kDconvNT + n]) + (s_red[2 * kDconvNT + n] + s_red[3 * kDconvNT + n]);
+    __syncthreads();
+  }
+}
+
+hipError_t launch_dconv_block(const DconvPlan &pl, float *out, const float *in1, const float *in2, float *del, float *coefs,
+                              float *part, unsigned *counters, int irsize, int vsize, int wp, hipStream_t s) {
+  if (pl.C < 1 || pl.C > kDconvMaxC || pl.G < 1 || (long)pl.C * pl.G < irsize || pl.VB < 1 || pl.VB > kDconvMaxVB)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_dconv_block, dim3(pl.G, pl.VB), dim3(256), 0, s, out, in1, in2, del, coefs, part, counters, irsize,
+                     vsize, wp, pl.C);
   return hipGetLastError();
 }
 

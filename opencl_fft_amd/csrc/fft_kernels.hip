@@ -277,7 +277,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     cpx *x = data + (active ? b : batch - 1) * (long)N;
     // software prefetch: the next transform's loads fly while this one is in the passes.
     // Always issued (index clamped to the last transform) so that it is straight-line code.
-    // (not for n = 8192: there two workgroups per CU overlap each other instead)
+    // (every LDS size has it — LdsGeom::PREFETCH; at n = 8192 it fits under the 128-VGPR cap and is worth 5 %)
     if constexpr (G::PREFETCH) {
       long gn = g + gridDim.x;
       gn = gn < groups ? gn : groups - 1;

@@ -131,7 +131,15 @@ hipError_t launch_pconv_pad(const float *in, long in_stride, cpx *work, int bins
 hipError_t launch_pconv_olap(const float *work, float *tail, float *out, int bins, int channels, hipStream_t s);
 
 // ---- direct convolution ----------------------------------------------------------
-hipError_t launch_dconv(float *out, const float *del, const float *coefs, int irsize, int vsize, int rp,
-                        hipStream_t s);
+struct DconvPlan {
+  int C;    // taps per workgroup
+  int G;    // chunks of the tap axis (grid x)
+  int VB;   // output blocks (grid y): block y takes the tiles of 64 outputs y, y + VB, ...
+};
+DconvPlan dconv_plan(int irsize, int vsize);
+// one block: out[0..vsize) from the rings as they stand with in1 (and in2) written at wp; files the block in the rings.
+// part: G x vsize floats, counters: VB zeroed words (both only touched when G > 1).  out must not overlap in1 / in2.
+hipError_t launch_dconv_block(const DconvPlan &pl, float *out, const float *in1, const float *in2, float *del, float *coefs,
+                              float *part, unsigned *counter, int irsize, int vsize, int wp, hipStream_t s);
 
 }  // namespace clfa

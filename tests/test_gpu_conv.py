@@ -188,6 +188,38 @@ def test_dconv_ring_wrap_vs_oracle(irsize, vsize, blocks):
         assert_parity(out, o.convolution(x[b * vsize:(b + 1) * vsize]), tol=5e-6, what="block %d" % b)
 
 
+@pytest.mark.parametrize("irsize,vsize,blocks,tv", [(96000, 64, 6, False), (5000, 100, 8, True), (3, 200, 4, False),
+                                                    (70000, 256, 5, True), (64, 64, 5, False), (300000, 16, 3, False),
+                                                    (4500, 40000, 2, True)])   # (more tiles than output blocks)
+def test_dconv_device_resident_blocks_vs_oracle(irsize, vsize, blocks, tv):
+    """the device-resident entry point (one launch per block; responses of more than one tap chunk hand their partial
+    sums to the last workgroup to arrive): a stream of blocks issued back to back, checked afterwards; the host entry
+    point then continues on the same object"""
+    import torch
+    s = util.lcg_half(11, irsize + 2 * vsize * (blocks + 1))
+    ir, x1, x2 = s[:irsize], s[irsize:irsize + vsize * (blocks + 1)], s[irsize + vsize * (blocks + 1):]
+    d, o = fa.Cldconv(0, irsize, vsize), oracle.Dconv(irsize, vsize)
+    assert d.get_cl_err() == 0 and d.push_ir(ir) == 0
+    o.push_ir(ir)
+    dx1, dx2 = torch.from_numpy(x1.copy()).cuda(), torch.from_numpy(x2.copy()).cuda()
+    dout = torch.zeros((blocks, vsize), device="cuda")
+    for b in range(blocks):
+        sl = slice(b * vsize, (b + 1) * vsize)
+        assert d.process_device(dout[b], dx1[sl], dx2[sl] if tv else None) == 0
+    torch.cuda.synchronize()
+    got = dout.cpu().numpy()
+    tol = max(2e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24)   # float32 sums of irsize terms in another order
+    for b in range(blocks):
+        sl = slice(b * vsize, (b + 1) * vsize)
+        want = o.convolution(x1[sl], x2[sl]) if tv else o.convolution(x1[sl])
+        assert_parity(got[b], want, tol=tol, what="block %d" % b)
+    sl = slice(blocks * vsize, (blocks + 1) * vsize)
+    out = np.zeros(vsize, np.float32)
+    assert (d.convolution(out, x1[sl], x2[sl]) if tv else d.convolution(out, x1[sl])) == 0
+    assert_parity(out, o.convolution(x1[sl], x2[sl]) if tv else o.convolution(x1[sl]), tol=tol, what="host call after")
+    assert d.process_device(dout[0], dout[0]) == -30   # out must not be an input
+
+
 def test_dconv_time_varying_vs_oracle():
     irsize, vsize, blocks = 32, 8, 12
     s = util.lcg_half(5, 2 * vsize * blocks)
