@@ -1085,7 +1085,8 @@ __global__ __launch_bounds__(256) void k_dconv_block(float *__restrict__ out, co
   const int per = (taps + 3) / 4;
   const int j0 = row * per, j1 = j0 + per < taps ? j0 + per : taps;
   for (int n0 = y * kDconvNT; n0 < vsize; n0 += VB * kDconvNT) {
-    __syncthreads();   // the previous tile's readers are done (first tile: s_k is complete)
+    // (no barrier here: the previous tile's readers of s_d passed the barrier behind their sums, and the first tile's
+    // window loads fly together with the coefficient loads above — the barrier below covers both)
     const int span = taps + kDconvNT - 1;
     const int base = (int)(((long)rp + n0 + h0) % end);
     for (int jb = tid; jb < span; jb += 8 * 256) {
