@@ -268,6 +268,9 @@ struct clfa_fft {
   // there; complex plans when CLFA_LDS14 says so — resolved at creation)
   bool lds14 = false;
   bool rlds15 = false;   // packed real size 65536: k_rfft_lds15 (two 16384-point runs per transform, one HBM pass)
+  bool c2x13 = false;    // complex n = 16384: k_cfft_2x13 (two 8192-point runs per transform, two workgroups per CU)
+  bool r2x13 = false;    // packed real size 32768: k_rfft_2x<13> (the same, with the pair maps in registers)
+  DevBuf half2;          // ... their tables: the n = 8192 lane tables + W_16384^t, t < 512
   long spread_below = 0; // real sizes 32768 / 65536: batches up to this run the four-step pair + pack kernel instead
   // any other length (extension): Bluestein around two power-of-two plans of length blue_m
   int blue_m = 0;
@@ -571,6 +574,26 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     if ((e = upload(p->w2, h.data(), sizeof(cpx) * n))) return e;
     p->tabs.w2 = (const cpx *)p->w2.p;
   }
+  if (!real && p->logn == 14 && !p->lds14) {
+    const char *sw = getenv("CLFA_C2X13");   // tuning switch, read once: 0 = complex n = 16384 on the four-step kernel
+    p->c2x13 = sw ? atoi(sw) != 0 : true;
+  }
+  if (real && p->logn == 14) {
+    const char *sw = getenv("CLFA_R2X13");   // tuning switch, read once: 0 = packed real size 32768 on k_fft_lds<14>
+    p->r2x13 = sw ? atoi(sw) != 0 : true;
+  }
+  if (p->c2x13 || p->r2x13) {
+    // the n = 8192 lane tables (as above) + the radix-2 step's lane constants W_16384^t
+    h.clear();
+    auto w = [&](long k, long nn) { h.push_back(mk((float)cos(k * 2 * kPI / nn), -(float)sin(k * 2 * kPI / nn))); };
+    for (int j = 0; j < 16; j++)
+      for (int t = 0; t < 16; t++) w(j * t, 256);
+    for (int k = 0; k < 4; k++)
+      for (int j = 0; j < 256; j++) w(((1 << k) * j) & 4095, 4096);
+    for (int t = 0; t < 512; t++) w(t, 8192);
+    for (int t = 0; t < 512; t++) w(t, 16384);
+    if ((e = upload(p->half2, h.data(), sizeof(cpx) * h.size()))) return e;
+  }
   return CLFA_SUCCESS;
 }
 
@@ -612,6 +635,7 @@ void clfa_fft_destroy(clfa_fft *p) {
   p->blue_b.release();
   p->blue_work.release();
   p->half.release();
+  p->half2.release();
   p->w2.release();
   p->four.release();
   p->scratch.release();
@@ -635,7 +659,8 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
   if (p->logn > kMaxLog) return "k_big_cols";
   if (p->blue_m) return "bluestein";
-  if (p->rlds15) return "k_rfft_lds15";
+  if (p->rlds15 || p->r2x13) return "k_rfft_2x";
+  if (p->c2x13) return "k_cfft_2x13";
   return (p->logn <= kLdsMaxLog || p->lds14) ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
 }
 
@@ -671,6 +696,18 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   const bool spread = p->real && batch <= p->spread_below;   // a few transforms: one workgroup each would be slower
   if (p->rlds15 && !spread) {
     HIP_TRY(launch_rfft_lds15(p->fwd, d, p->tabs, batch, p->di, s));
+    return CLFA_SUCCESS;
+  }
+  if (p->r2x13 && !spread) {
+    FftTables t2 = p->tabs;
+    t2.half = (const cpx *)p->half2.p;
+    HIP_TRY(launch_rfft_2x13(p->fwd, d, t2, batch, p->di, s));
+    return CLFA_SUCCESS;
+  }
+  if (p->c2x13 && batch * 4 > p->di.num_cus) {   // (fewer transforms: spread over the four-step column / row kernels)
+    FftTables t2 = p->tabs;
+    t2.half = (const cpx *)p->half2.p;
+    HIP_TRY(launch_cfft_2x13(p->fwd, scale, d, t2, batch, p->di, s));
     return CLFA_SUCCESS;
   }
   if (p->logn <= kLdsMaxLog || (p->lds14 && !spread)) {

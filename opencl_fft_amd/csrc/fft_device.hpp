@@ -892,13 +892,41 @@ template <bool FWD, int S> CLFA_HD cpx pair_tw14(cpx c0, int u, int q, int lane)
   }
   return w;
 }
+// The same for 8192-point sub-transforms (packed real size 32768, M = 8192): i = pair_index<13, 4>(lane, u, q),
+//   j = lane + 512 u (u = 0..3):  q = 0 -> i = j, 1 -> 4096 - j   (lane 0, u = 0: i = 0, 2048).
+// S = 0: P = 16384, S = 1: P = 32768.
+template <bool FWD, int S> CLFA_HD cpx pair_tw13(cpx c0, int u, int q, int lane) {
+  static_assert(S == 0 || S == 1, "");
+  // W_P^(512 u): W_32^u (S = 0), W_64^u (S = 1)
+  constexpr float cu[2][4] = {{1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f},
+                              {1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f}};
+  constexpr float su[2][4] = {{0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f},
+                              {0.0f, 0.09801714032956060199f, 0.19509032201612826785f, 0.29028467725446236764f}};
+  cpx z = c0;
+  if (u == 1) z = ctw<FWD>(z, cu[S][1], su[S][1]);
+  if (u == 2) z = ctw<FWD>(z, cu[S][2], su[S][2]);
+  if (u == 3) z = ctw<FWD>(z, cu[S][3], su[S][3]);
+  if (q == 0) return z;
+  cpx w;   // W_P^4096 conj(z): S = 0: -+i conj(z); S = 1: W_8 conj(z)
+  if (S == 0) w = FWD ? mk(-z.y, -z.x) : mk(z.y, z.x);
+  else w = ctw<FWD>(mk(z.x, -z.y), kC8, kC8);
+  if (u == 0 && lane == 0) w = S == 0 ? mk(kC8, FWD ? -kC8 : kC8) : mk(kC16, FWD ? -kS16 : kS16);   // W_P^2048
+  return w;
+}
+template <int LOGC, bool FWD, int S> CLFA_HD cpx pair_tw2x(cpx c0, int u, int q, int lane) {
+  static_assert(LOGC == 13 || LOGC == 14, "sub-transforms of 8192 or 16384 points");
+  if constexpr (LOGC == 14) return pair_tw14<FWD, S>(c0, u, q, lane);
+  else return pair_tw13<FWD, S>(c0, u, q, lane);
+}
 constexpr int kM15 = 16384;
 // forward: slot (u, q) of lane `lane`: A[i], A[M - i], B[i], B[M - i] (for i = 0: A[0], A[M / 2], ...) ->
 // st(position, packed spectrum value) x 4.  g0 = W_2M^lane, h0 = W_4M^lane (the r2c table's entries 2 lane, lane).
-template <class St> CLFA_HD void rfft15_fwd_slot(int lane, int u, int q, int i, cpx ai, cpx aj, cpx bi, cpx bj, cpx g0,
-                                                 cpx h0, St st) {
+// M = 2^LOGC is the length of the sub-transforms.
+template <int LOGC, class St> CLFA_HD void rfft2x_fwd_slot(int lane, int u, int q, int i, cpx ai, cpx aj, cpx bi, cpx bj,
+                                                          cpx g0, cpx h0, St st) {
+  constexpr int M = 1 << LOGC;
   const bool first = i == 0;
-  const cpx g = pair_tw14<true, 0>(g0, u, q, lane), h = pair_tw14<true, 1>(h0, u, q, lane);
+  const cpx g = pair_tw2x<LOGC, true, 0>(g0, u, q, lane), h = pair_tw2x<LOGC, true, 1>(h0, u, q, lane);
   const cpx gp = first ? mk(0.f, -1.f) : mk(-g.x, g.y);       // W_2M^(M - i) = -conj(g);  W_2M^(M / 2) = -i
   const cpx hp = first ? mk(kC8, -kC8) : mk(-h.y, -h.x);      // W_4M^(M - i) = -i conj(h);  W_4M^(M / 2) = W_8
   const cpx t1 = cmul(g, bi), t2 = cmul(gp, bj);
@@ -916,25 +944,26 @@ template <class St> CLFA_HD void rfft15_fwd_slot(int lane, int u, int q, int i, 
     o1a = mk((zi_a.x + zi_a.y) * .5f, (zi_a.x - zi_a.y) * .5f);
     o1b = zp_b;
   }
-  const int i2 = first ? kM15 / 2 : i;
+  const int i2 = first ? M / 2 : i;
   st(i, o1a);
-  st(first ? kM15 : 2 * kM15 - i, o1b);
-  st(kM15 - i2, o2a);
-  st(kM15 + i2, o2b);
+  st(first ? M : 2 * M - i, o1b);
+  st(M - i2, o2a);
+  st(M + i2, o2b);
 }
 // positions of the slot's four packed bins: pair (i, 2M - i) and pair (M - i, M + i); the slot with i = 0 (lane 0's
 // first) holds (0, M) and (M / 2, 3M / 2)
-CLFA_HD int rfft15_pos(int i, int which) {
+template <int LOGC> CLFA_HD int rfft2x_pos(int i, int which) {
+  constexpr int M = 1 << LOGC;
   const bool first = i == 0;
-  const int i2 = first ? kM15 / 2 : i;
-  return which == 0 ? i : which == 1 ? (first ? kM15 : 2 * kM15 - i) : which == 2 ? kM15 - i2 : kM15 + i2;
+  const int i2 = first ? M / 2 : i;
+  return which == 0 ? i : which == 1 ? (first ? M : 2 * M - i) : which == 2 ? M - i2 : M + i2;
 }
-// inverse: the four packed bins of the slot (x1a .. x2b at rfft15_pos(i, 0 .. 3)) -> inputs of the two transposed
+// inverse: the four packed bins of the slot (x1a .. x2b at rfft2x_pos(i, 0 .. 3)) -> inputs of the two transposed
 // chains: oa / ob = value at sub-position i, pa / pb = value at its partner M - i (pass_first_paired's oi[k] / oj[k])
-CLFA_HD void rfft15_inv_slot(int lane, int u, int q, int i, cpx g0, cpx h0, cpx x1a, cpx x1b, cpx x2a, cpx x2b, cpx &oa,
-                             cpx &pa, cpx &ob, cpx &pb) {
+template <int LOGC> CLFA_HD void rfft2x_inv_slot(int lane, int u, int q, int i, cpx g0, cpx h0, cpx x1a, cpx x1b, cpx x2a,
+                                                 cpx x2b, cpx &oa, cpx &pa, cpx &ob, cpx &pb) {
   const bool first = i == 0;
-  const cpx g = pair_tw14<false, 0>(g0, u, q, lane), h = pair_tw14<false, 1>(h0, u, q, lane);
+  const cpx g = pair_tw2x<LOGC, false, 0>(g0, u, q, lane), h = pair_tw2x<LOGC, false, 1>(h0, u, q, lane);
   const cpx gp = first ? mk(0.f, 1.f) : mk(-g.x, g.y);
   const cpx hp = first ? mk(kC8, kC8) : mk(h.y, h.x);
   cpx z1a, z1b, z2a, z2b;

@@ -439,12 +439,14 @@ __device__ __forceinline__ cpx ld_r15(const cpx *p) {
 struct R15Off {
   int v, s;
 };
-__device__ __forceinline__ R15Off rfft15_off(const XferBuf &b, int t, int u, int q, int which) {
-  constexpr int M = kM15, NB = 4096, T = 1024;
-  if (u == 0) return R15Off{rfft15_pos(pair_index<14, 4>(t, 0, q), which) * 8, 0};
-  // i = (q < 2 ? +j : -j) + ci;  position = which 0: i, 1: 2M - i, 2: M - i, 3: M + i
-  const bool ineg = q >= 2;
-  const int ci = q == 0 ? 0 : q == 1 ? NB : q == 2 ? 2 * NB : NB;
+// LOGC: the sub-transforms' length (14: real size 65536, T = 1024 lanes, four pairs per u; 13: real size 32768,
+// T = 512 lanes, two pairs per u — pair_index<13, 4>: q = 0 -> i = j, 1 -> 4096 - j)
+template <int LOGC> __device__ __forceinline__ R15Off rfft2x_off(const XferBuf &b, int t, int u, int q, int which) {
+  constexpr int M = 1 << LOGC, NB = 4096, T = M / 16;
+  if (u == 0) return R15Off{rfft2x_pos<LOGC>(pair_index<LOGC, 4>(t, 0, q), which) * 8, 0};
+  // i = +j + ci or -j + ci;  position = which 0: i, 1: 2M - i, 2: M - i, 3: M + i
+  const bool ineg = LOGC == 14 ? q >= 2 : q >= 1;
+  const int ci = LOGC == 14 ? (q == 0 ? 0 : q == 1 ? NB : q == 2 ? 2 * NB : NB) : (q == 0 ? 0 : NB);
   const bool neg = (which == 1 || which == 2) ? !ineg : ineg;                       // sign of j in the position
   const int c = which == 0 ? ci : which == 1 ? 2 * M - ci : which == 2 ? M - ci : M + ci;   // position = c +- j
   return neg ? R15Off{b.vd, (c - u * T - T) * 8} : R15Off{b.va, (c + u * T) * 8};
@@ -454,29 +456,38 @@ __device__ __forceinline__ void st_nt16(cpx *p, f4v v) {
   else *reinterpret_cast<f4v *>(p) = v;
 }
 
-template <bool FWD, bool SCALE>
-__global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
-                                                        const cpx *__restrict__ w2_g, long batch) {
-  using G = LdsGeom<14>;
-  constexpr int LOGN = 14, LOGE = 4, E = 16, T = 1024, R = 4;
+// k_rfft_2x<14>: real size 65536, one 1024-lane workgroup per CU (formerly k_rfft_lds15);
+// k_rfft_2x<13>: real size 32768, 512 lanes and 71 KiB of LDS — TWO workgroups per CU, which overlap each other's
+// memory phases (k_fft_lds<14> with its pair maps puts one 1024-lane workgroup on a CU)
+template <int LOGC, bool FWD, bool SCALE>
+__global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_rfft_2x(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
+                                                                 const cpx *__restrict__ w2_g, long batch) {
+  using G = LdsGeom<LOGC>;
+  constexpr int LOGN = LOGC, LOGE = 4, E = 16, M = 1 << LOGC, T = M / E, R = 1 << pass_rem_logr(LOGC, LOGE);
   __shared__ cpx s_tab[kLane13Lds];
   __shared__ cpx s_x[G::PADN];
   const int tid = threadIdx.x;
   for (int i = tid; i < kLane13Lds; i += T) s_tab[i] = tab_g[i];
-  // lane constants kept across the batch loop: W_16384^tid and W_65536^tid only (4 VGPRs; the kernel runs under
-  // the 128-VGPR cap of a 1024-lane workgroup) — W_16384^(2 tid), ^(3 tid) and W_32768^tid are their products
+  // lane constants kept across the batch loop: W_M^tid and W_4M^tid only (4 VGPRs; the kernel runs under the 128-VGPR
+  // cap) — W_M^(2 tid), ^(3 tid) and W_2M^tid are their products
   const cpx wl0 = tab_g[kLane13Lds + tid];
-  const cpx h0 = w2_g[tid];   // W_65536^tid (the plan's sign)
+  const cpx h0 = w2_g[tid];   // W_4M^tid (the plan's sign)
   cpx *xb = s_x;
   __syncthreads();
 #pragma unroll 1
   for (long b = blockIdx.x; b < batch; b += gridDim.x) {
     int t = tid;   // opaque per iteration: LDS / global offsets are recomputed, not kept live across the loop
     asm volatile("" : "+v"(t));
-    const cpx wl1 = cmul(wl0, wl0);
-    const LaneTab14 tab{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0, wl1, cmul(wl0, wl1)};
-    const cpx g0 = cmul(h0, h0);   // W_32768^tid
-    cpx *x = data + b * (long)(2 * kM15);
+    const auto tab = [&]() {
+      if constexpr (LOGC == 14) {
+        const cpx wl1 = cmul(wl0, wl0);
+        return LaneTab14{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0, wl1, cmul(wl0, wl1)};
+      } else {
+        return LaneTab13{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0};
+      }
+    }();
+    const cpx g0 = cmul(h0, h0);   // W_2M^tid
+    cpx *x = data + b * (long)(2 * M);
     const XferBuf xo{__builtin_amdgcn_make_buffer_rsrc(x, 0, 0x7fffffff, 0x00020000), t * 8, (T - t) * 8};
     cpx va[E], vb[E];
     if constexpr (FWD) {
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
       pass_compute<LOGN, LOGE, 0, true>(va, t, tab);
       wg_passes_pair<LOGN, LOGE, 0, true>(va, vb, t, tab, xb);   // staggered: one chain's LDS transfers under the other's passes
       if constexpr (SCALE) {
-        constexpr float inv = 1.0f / (float)(2 * kM15);
+        constexpr float inv = 1.0f / (float)(2 * M);
 #pragma unroll
         for (int e = 0; e < E; e++) {
           va[e] = cscale(va[e], inv);
@@ -508,8 +519,8 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {
         // (flat addresses for the forward kernel's stores: buffer-addressed they were measured 2 % slower)
-        rfft15_fwd_slot(t, k / R, k % R, pair_index<LOGN, LOGE>(t, k / R, k % R), ai[k], aj[k], bi[k], bj[k], g0, h0,
-                        [&](int pos, cpx v) { st_nt(x + pos, v); });
+        rfft2x_fwd_slot<LOGC>(t, k / R, k % R, pair_index<LOGN, LOGE>(t, k / R, k % R), ai[k], aj[k], bi[k], bj[k], g0, h0,
+                              [&](int pos, cpx v) { st_nt(x + pos, v); });
         __builtin_amdgcn_sched_barrier(0);   // slot by slot: hoisted, the eight slots' twiddles spill
       }
     } else {
@@ -519,14 +530,14 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
       for (int k = 0; k < E / 2; k++)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-          const R15Off o = rfft15_off(xo, t, k / R, k % R, w);
+          const R15Off o = rfft2x_off<LOGC>(xo, t, k / R, k % R, w);
           raw[4 * k + w] = ld_buf<CLFA_NT_LD_R15 != 0>(xo, o.v, o.s);
         }
 #pragma unroll
       for (int k = 0; k < E / 2; k++) {
         const int i = pair_index<LOGN, LOGE>(t, k / R, k % R);
-        rfft15_inv_slot(t, k / R, k % R, i, g0, h0, raw[4 * k], raw[4 * k + 1], raw[4 * k + 2], raw[4 * k + 3], oa[k], pa[k],
-                        ob[k], pb[k]);
+        rfft2x_inv_slot<LOGC>(t, k / R, k % R, i, g0, h0, raw[4 * k], raw[4 * k + 1], raw[4 * k + 2], raw[4 * k + 3], oa[k],
+                              pa[k], ob[k], pb[k]);
       }
       constexpr int L1 = pass_last_logns(LOGN, LOGE) - LOGE;
       // staggered (fft_wg.hpp, wg_passes_dif_pair): one chain's scatter drains under the other's butterflies
@@ -551,8 +562,92 @@ __global__ __launch_bounds__(1024, 4) void k_rfft_lds15(cpx *__restrict__ data, 
 hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
   if (batch <= 0) return hipSuccess;
   const int grid = (int)(batch < di.num_cus ? batch : di.num_cus);   // one 1024-lane workgroup per CU
-  if (fwd) hipLaunchKernelGGL((k_rfft_lds15<true, true>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
-  else hipLaunchKernelGGL((k_rfft_lds15<false, false>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
+  if (fwd) hipLaunchKernelGGL((k_rfft_2x<14, true, true>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
+  else hipLaunchKernelGGL((k_rfft_2x<14, false, false>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
+  return hipGetLastError();
+}
+// real size 32768: t.half = the n = 8192 lane tables (kLane13Size), t.w2 = the plan's r2c table (16384 entries)
+hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  const long cap = 2L * di.num_cus;   // two 512-lane workgroups per CU
+  const int grid = (int)(batch < cap ? batch : cap);
+  if (fwd) hipLaunchKernelGGL((k_rfft_2x<13, true, true>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch);
+  else hipLaunchKernelGGL((k_rfft_2x<13, false, false>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// complex n = 16384 as TWO 8192-point runs (decimation in time: even and odd samples — one 16-byte load per lane
+// brings both) through the n = 8192 machinery, staggered through one exchange buffer (wg_passes_pair), and a radix-2
+// step in registers: Z[i] = A[i] + W_16384^i B[i], Z[i + 8192] = A[i] - W_16384^i B[i].  512 lanes, 71 KiB of LDS:
+// two workgroups share a CU and overlap each other's memory phases — the whole-transform-in-LDS forms (k_fft_lds<14>
+// with 1024 lanes, the persistent four-step kernel) put ONE workgroup on a CU, and its load, pass and store phases
+// follow one another.  W_16384^(tid + 512 e) = (lane constant W_16384^tid) x (compile-time W_32^e).
+// ---------------------------------------------------------------------------------
+template <bool FWD, bool SCALE>
+__global__ __launch_bounds__(512, 4) void k_cfft_2x13(cpx *__restrict__ data, const cpx *__restrict__ tab_g, long batch) {
+  using G = LdsGeom<13>;
+  constexpr int LOGN = 13, LOGE = 4, E = 16, T = 512, M = 8192;
+  __shared__ cpx s_tab[kLane13Lds];
+  __shared__ cpx s_x[G::PADN];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kLane13Lds; i += T) s_tab[i] = tab_g[i];
+  const cpx wl0 = tab_g[kLane13Lds + tid];    // W_8192^tid
+  const cpx h0 = tab_g[kLane13Size + tid];    // W_16384^tid (forward sign, like every table)
+  cpx *xb = s_x;
+  __syncthreads();
+#pragma unroll 1
+  for (long b = blockIdx.x; b < batch; b += gridDim.x) {
+    int t = tid;   // opaque per iteration: LDS / global offsets are recomputed, not kept live across the loop
+    asm volatile("" : "+v"(t));
+    const LaneTab13 tab{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0};
+    cpx *x = data + b * (long)(2 * M);
+    cpx va[E], vb[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const f4v q = ld_nt16(x + 2 * (t + T * e));
+      va[e] = mk(q.x, q.y);
+      vb[e] = mk(q.z, q.w);
+    }
+    pass_compute<LOGN, LOGE, 0, FWD>(va, t, tab);
+    wg_passes_pair<LOGN, LOGE, 0, FWD, false>(va, vb, t, tab, xb);
+    // radix-2 step: position i = t + T e
+    constexpr float c32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                               0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                               0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
+                               -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                               -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float s32[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                               0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                               0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
+                               0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                               0.38268343236508977173f, 0.19509032201612826785f};
+    constexpr float inv = SCALE ? 1.0f / (float)(2 * M) : 1.0f;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const cpx w = e == 0 ? h0 : ctw<true>(h0, c32[e], s32[e]);   // W_16384^(t + 512 e), forward sign
+      const cpx p = cmulc<!FWD>(vb[e], w);
+      cpx o0 = cadd(va[e], p), o1 = csub(va[e], p);
+      if constexpr (SCALE) {
+        o0 = cscale(o0, inv);
+        o1 = cscale(o1, inv);
+      }
+      st_nt(x + t + T * e, o0);
+      st_nt(x + M + t + T * e, o1);
+      __builtin_amdgcn_sched_barrier(0);   // element by element: hoisted, the sixteen twiddles spill
+    }
+  }
+}
+
+hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
+                            hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  const long cap = 2L * di.num_cus;   // two 512-lane workgroups per CU
+  const int grid = (int)(batch < cap ? batch : cap);
+  if (fwd && scale) hipLaunchKernelGGL((k_cfft_2x13<true, true>), dim3(grid), dim3(512), 0, s, data, t.half, batch);
+  else if (fwd) hipLaunchKernelGGL((k_cfft_2x13<true, false>), dim3(grid), dim3(512), 0, s, data, t.half, batch);
+  else if (!scale) hipLaunchKernelGGL((k_cfft_2x13<false, false>), dim3(grid), dim3(512), 0, s, data, t.half, batch);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -45,16 +45,18 @@ __device__ __forceinline__ void wg_passes_dif_after(cpx (&v)[1 << LOGE], int t, 
 // compute, then all of them wait for their scattered writes to drain (16 ds_write_b64 per lane move at a third of the
 // LDS read rate), then all of them gather — and the chains, not the memory, bound the kernel.
 // Same passes, same number of barriers as two wg_passes calls.
-// Precondition: va holds the OUTPUT of pass LOGNS (computed), vb its INPUT (not yet computed); last pass paired.
-template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
+// Precondition: va holds the OUTPUT of pass LOGNS (computed), vb its INPUT (not yet computed).  PAIRLAST: the last
+// pass is pass_last_paired (packed real transforms); otherwise both end as wg_passes does, at positions tid + T*e.
+template <int LOGN, int LOGE, int LOGNS, bool FWD, bool PAIRLAST = true, class Tab>
 __device__ __forceinline__ void wg_passes_pair(cpx (&va)[1 << LOGE], cpx (&vb)[1 << LOGE], int t, const Tab &tab, cpx *xb) {
   constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS), NEXT = LOGNS + LOGR;
-  static_assert(NEXT < LOGN, "ends in pass_last_paired");
+  static_assert(NEXT < LOGN, "at least one more pass");
+  constexpr bool LAST = NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN;   // the pass after this one is the last
   __syncthreads();   // everybody is done reading the previous exchange
   pass_scatter_padded<LOGN, LOGE, LOGNS>(va, t, xb);
   pass_compute<LOGN, LOGE, LOGNS, FWD>(vb, t, tab);          // under a's LDS writes
   __syncthreads();
-  if constexpr (NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN) {
+  if constexpr (LAST && PAIRLAST) {
     pass_last_paired<LOGN, LOGE, FWD>(va, t, tab, xb, [&]() {
       __syncthreads();   // a's gather is complete in every wave
       pass_scatter_padded<LOGN, LOGE, LOGNS>(vb, t, xb);     // ... and b's writes run under a's last butterflies
@@ -68,7 +70,8 @@ __device__ __forceinline__ void wg_passes_pair(cpx (&va)[1 << LOGE], cpx (&vb)[1
     pass_compute<LOGN, LOGE, NEXT, FWD>(va, t, tab);         // under b's LDS writes
     __syncthreads();
     pass_gather_padded<LOGN, LOGE>(vb, t, xb);
-    wg_passes_pair<LOGN, LOGE, NEXT, FWD>(va, vb, t, tab, xb);
+    if constexpr (LAST) pass_compute<LOGN, LOGE, NEXT, FWD>(vb, t, tab);
+    else wg_passes_pair<LOGN, LOGE, NEXT, FWD, PAIRLAST>(va, vb, t, tab, xb);
   }
 }
 

@@ -43,6 +43,13 @@ const char *name_fft_lds(int logn, bool fwd, int mode);
 // packed real size 65536 (n = 32768): two runs of the 16384-point machinery per transform, radix-2 step and pair
 // map in registers; t.half = the n = 16384 lane tables (kLane14Size), t.w2 = the plan's r2c table (n entries)
 hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
+// packed real size 32768 the same way on two 8192-point runs (two 512-lane workgroups per CU); t.half = the n = 8192
+// lane tables (kLane13Size), t.w2 = the plan's r2c table
+hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
+// complex n = 16384 as two 8192-point runs + a radix-2 step in registers; t.half = the n = 8192 lane tables
+// (kLane13Size) followed by W_16384^t, t < 512
+hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
+                            hipStream_t s);
 
 // four-step FFT, n = 2^logn in (2^kLdsMaxLog, 2^kMaxLog]; scratch = fourstep_grid() * n complex
 // (n = 65536 with more than a few transforms runs the resident kernel below and uses the first

@@ -381,9 +381,9 @@ template <int LOGN> static int lane_tables() {
   return bad != 0;
 }
 
-// ---- packed real size 65536 on two 16384-point sub-transforms (rfft15_fwd_slot / rfft15_inv_slot) -----
-static int rfft15() {
-  constexpr int LOGN = 14, LOGE = 4, M = 1 << LOGN, n = 2 * M, E = 16, T = M / E, R = 4, U = 4;
+// ---- packed real sizes 32768 / 65536 on two 8192- / 16384-point sub-transforms (rfft2x_fwd_slot / rfft2x_inv_slot) -----
+template <int LOGN> static int rfft2x() {
+  constexpr int LOGE = 4, M = 1 << LOGN, n = 2 * M, E = 16, T = M / E, R = 1 << pass_rem_logr(LOGN, LOGE), U = E / R;
   std::vector<cpx> blob, z(n), half(n / 2), w2f(n), w2i(n), lds(lds_padded_size(n));
   auto tabs = make_lane_tabs<LOGN>(blob);
   unsigned s = 31337u;
@@ -404,7 +404,7 @@ static int rfft15() {
     constexpr int T15 = n / E;
     for (int tid = 0; tid < T15; tid++)
       for (int e = 0; e < E; e++) regs[tid * E + e] = z[tid + T15 * e];
-    run<15, LOGE, 0, true>(regs, half, lds);
+    run<LOGN + 1, LOGE, 0, true>(regs, half, lds);
     for (int tid = 0; tid < T15; tid++)
       for (int e = 0; e < E; e++) Z[tid + T15 * e] = cscale(regs[tid * E + e], 1.0f / (float)n);
   }
@@ -430,7 +430,7 @@ static int rfft15() {
       (void)i; bi[k] = cscale(ci, 1.0f / (float)n); bj[k] = cscale(cj, 1.0f / (float)n);
     });
     for (int k = 0; k < 8; k++)
-      rfft15_fwd_slot(tid, k / R, k % R, ii[k], ai[k], aj[k], bi[k], bj[k], w2f[2 * tid], w2f[tid],
+      rfft2x_fwd_slot<LOGN>(tid, k / R, k % R, ii[k], ai[k], aj[k], bi[k], bj[k], w2f[2 * tid], w2f[tid],
                       [&](int pos, cpx v) { got[pos] = v; seen[pos]++; });
   }
   for (int i = 0; i < n; i++) if (seen[i] != 1) bad |= 1;
@@ -449,7 +449,7 @@ static int rfft15() {
     constexpr int T15 = n / E;
     for (int tid = 0; tid < T15; tid++)
       for (int e = 0; e < E; e++) regs[tid * E + e] = y[tid + T15 * e];
-    run<15, LOGE, 0, false>(regs, half, lds);
+    run<LOGN + 1, LOGE, 0, false>(regs, half, lds);
     for (int tid = 0; tid < T15; tid++)
       for (int e = 0; e < E; e++) wanti[tid + T15 * e] = regs[tid * E + e];
   }
@@ -462,11 +462,11 @@ static int rfft15() {
         const int k = u * R + q, i = pair_index<LOGN, LOGE>(tid, u, q);
         cpx in[4];
         for (int w = 0; w < 4; w++) {
-          const int pos = rfft15_pos(i, w);
+          const int pos = rfft2x_pos<LOGN>(i, w);
           seen[pos]++;
           in[w] = z[pos];
         }
-        rfft15_inv_slot(tid, u, q, i, w2i[2 * tid], w2i[tid], in[0], in[1], in[2], in[3], OA[tid * 8 + k], PA[tid * 8 + k],
+        rfft2x_inv_slot<LOGN>(tid, u, q, i, w2i[2 * tid], w2i[tid], in[0], in[1], in[2], in[3], OA[tid * 8 + k], PA[tid * 8 + k],
                         OB[tid * 8 + k], PB[tid * 8 + k]);
       }
   for (int i = 0; i < n; i++) if (seen[i] != 1) bad |= 4;
@@ -485,7 +485,7 @@ static int rfft15() {
   }
   const double e_i = rel_l2(goti, wanti);
   if (!(e_i < 3e-7)) bad |= 8;
-  printf("real size 65536 on two 16384-point sub-transforms: forward relL2 %.3g (max %.3g), inverse relL2 %.3g%s\n", e_f,
+  printf("real size %d on two %d-point sub-transforms: forward relL2 %.3g (max %.3g), inverse relL2 %.3g%s\n", 2 * n, M, e_f,
          mx / mxref, e_i, bad ? "  FAIL" : "");
   if (bad) printf("  flags %d\n", bad);
   return bad != 0;
@@ -506,7 +506,7 @@ int main() {
             paired<13, 4>() | paired<4, 3>() | paired<5, 3>() | paired<7, 3>();
   g_fail |= paired<14, 4>();
   g_fail |= lane_tables<13>() | lane_tables<14>();
-  g_fail |= rfft15();
+  g_fail |= rfft2x<14>() | rfft2x<13>();
   puts(g_fail ? "FAIL" : "OK");
   return g_fail;
 }

@@ -4,6 +4,8 @@ libclfft_amd.so) against the CPU oracle and the reference's golden vectors.
 Bar: integer/index work bit-exact; float32 spectra within
 TOL = 1e-6 in both ||y-ref||2/||ref||2 and max|y-ref|/max|ref|.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -155,27 +157,42 @@ def test_cfft_batched_kernels_vs_reference_vectors(n):
     kernel — and EVERY transform of the batch is compared with the reference's vector."""
     batch = 70
     x = np.tile(util.lcg_complex(12345, n), (batch, 1))
-    for fwd in (True, False):
-        plan = fa.Clcfft(0, n, fwd)
-        assert plan.kernel_name() == ("k_fft_res16" if n == 65536 else "k_fft_4step")
+    want = {65536: "k_fft_res16", 32768: "k_fft_4step", 16384: "k_cfft_2x13"}[n]
+    cases = [(True, want), (False, want)]
+    if n == 16384:   # ... and the four-step kernel of that length, still in the library behind its plan-time switch
+        cases += [(True, "k_fft_4step"), (False, "k_fft_4step")]
+    for fwd, kernel in cases:
+        if kernel != want:
+            os.environ["CLFA_C2X13"] = "0"
+        try:
+            plan = fa.Clcfft(0, n, fwd)
+        finally:
+            os.environ.pop("CLFA_C2X13", None)
+        assert plan.kernel_name() == kernel
         y = x.copy()
         assert plan.transform(y) == 0
         ref = golden("g4_cfft%d_%s_dec" % (n, "fwd" if fwd else "inv"))
         for b in range(batch):
-            assert_parity(util.decimate(y[b]), ref, what="n=%d fwd=%s transform %d vs reference" % (n, fwd, b))
+            assert_parity(util.decimate(y[b]), ref, what="n=%d fwd=%s %s transform %d vs reference" % (n, fwd, kernel, b))
         assert np.array_equal(y.view(np.uint32), np.tile(y[0], (batch, 1)).view(np.uint32)), "transforms of one batch differ"
 
 
-@pytest.mark.parametrize("size", [32768, 65536, 131072])
-def test_rfft_batched_kernels_vs_reference_vectors(size):
+@pytest.mark.parametrize("size,kernel", [(32768, "k_rfft_2x"), (32768, "k_fft_lds"), (65536, "k_rfft_2x"), (131072, None)])
+def test_rfft_batched_kernels_vs_reference_vectors(size, kernel):
     """Clrfft::transform (cl_fft.cpp:267-296) vectors against the one-pass real kernels: more than 32 transforms select
-    k_fft_lds<14> (size 32768) / k_rfft_lds15 (size 65536) instead of the spread path a single transform takes; every
+    k_rfft_2x (two 8192-point runs for size 32768, two 16384-point runs for size 65536; size 32768 also on k_fft_lds<14>,
+    still in the library behind its plan-time switch) instead of the spread path a single transform takes; every
     transform of the batch against the reference's forward, round-trip and arbitrary-spectrum inverse vectors, bin M/2
     (the reference's never-conjugated self-paired bin, cl_fft.cpp:278) included."""
     batch, m = 70, size // 2
-    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
-    if size <= 65536:
-        assert f.kernel_name() == ("k_rfft_lds15" if size == 65536 else "k_fft_lds")
+    if kernel == "k_fft_lds":
+        os.environ["CLFA_R2X13"] = "0"
+    try:
+        f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+    finally:
+        os.environ.pop("CLFA_R2X13", None)
+    if kernel is not None:
+        assert f.kernel_name() == kernel and i.kernel_name() == kernel
     x = np.tile(util.lcg_sym(12345, size), (batch, 1))
     buf = x.copy().view(np.complex64)
     assert f.transform(buf) == 0                                   # in place, batch x m packed bins
@@ -267,7 +284,7 @@ def test_rfft_batched_in_place(size, batch):
 @pytest.mark.parametrize("size,batch", [(32768, 1), (32768, 32), (32768, 33), (32768, 259), (32768, 1030),
                                         (65536, 1), (65536, 32), (65536, 33), (65536, 257), (65536, 700)])
 def test_rfft_fused_big_sizes_ragged_batches(size, batch):
-    """real sizes 32768 (k_fft_lds<14>, 1024 lanes) and 65536 (k_rfft_lds15) — one persistent workgroup per CU:
+    """real sizes 32768 (k_rfft_2x<13>, two 512-lane workgroups per CU) and 65536 (k_rfft_2x<14>, one of 1024 lanes):
     fewer transforms than CUs, one more than a whole number of rounds, several rounds; up to 32 transforms run
     spread over the four-step pair + pack kernel instead (both sides of that switch are here); device-resident,
     a few transforms against the oracle, every transform through the round trip"""
@@ -276,7 +293,7 @@ def test_rfft_fused_big_sizes_ragged_batches(size, batch):
     d = torch.rand((batch, size), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
     x = d.clone()
     f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
-    assert f.kernel_name() == ("k_rfft_lds15" if size == 65536 else "k_fft_lds")
+    assert f.kernel_name() == "k_rfft_2x"
     assert f.exec_device(d, batch) == 0
     pick = sorted({0, batch // 2, batch - 1})
     spec = d[pick].cpu().numpy().view(np.complex64)

@@ -1,9 +1,11 @@
-"""interleaved A/B of a plan-time environment switch: python ab_env.py <VAR> <n> [real]"""
+"""interleaved A/B of a plan-time environment switch: python ab_env.py <VAR>[=value] <n> [real]
+("off" = variable unset, "on" = variable set to value, default 1)"""
 import os, sys, statistics
 sys.path.insert(0, ".")
 import torch
 import opencl_fft_amd as fa
 var, n = sys.argv[1], int(sys.argv[2])
+var, val = (var.split("=") + ["1"])[:2]
 real = len(sys.argv) > 3
 batch = (1 << 27) // n
 d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
@@ -13,7 +15,7 @@ def mk():
     return [fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)]
 os.environ.pop(var, None)
 off = mk()
-os.environ[var] = "1"
+os.environ[var] = val
 on = mk()
 os.environ.pop(var, None)
 print("kernels:", off[0].kernel_name() if hasattr(off[0], "kernel_name") else "?", on[0].kernel_name() if hasattr(on[0], "kernel_name") else "?")

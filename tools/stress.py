@@ -20,7 +20,7 @@ for n, batch, iters in [(65536, 4096, 300), (65536, 777, 300), (32768, 8192, 200
     print("n=%d batch=%d: %d round trips, worst relL2 after 10 round trips %.2e" % (n, batch, iters, worst), flush=True)
 print("OK")
 
-# the one-workgroup-per-CU real kernels (k_fft_lds<14>, k_rfft_lds15): r2c then c2r is the identity
+# the one-workgroup-per-CU real kernels (k_rfft_2x<13>, k_rfft_2x<14>): r2c then c2r is the identity
 for size, batch, iters in [(32768, 8192, 200), (32768, 259, 300), (65536, 4096, 200), (65536, 257, 300)]:
     f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
     x = torch.rand((batch, size), device="cuda") * 2 - 1
