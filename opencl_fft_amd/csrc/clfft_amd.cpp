@@ -270,6 +270,7 @@ struct clfa_fft {
   bool rlds15 = false;   // packed real size 65536: k_rfft_lds15 (two 16384-point runs per transform, one HBM pass)
   bool c2x13 = false;    // complex n = 16384: k_cfft_2x13 (two 8192-point runs per transform, two workgroups per CU)
   bool r2x13 = false;    // packed real size 32768: k_rfft_2x<13> (the same, with the pair maps in registers)
+  bool c2x14 = false;    // complex n = 32768 on two 16384-point runs (experiment, CLFA_C2X14=1)
   DevBuf half2;          // ... their tables: the n = 8192 lane tables + W_16384^t, t < 512
   long spread_below = 0; // real sizes 32768 / 65536: batches up to this run the four-step pair + pack kernel instead
   // any other length (extension): Bluestein around two power-of-two plans of length blue_m
@@ -582,6 +583,19 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     const char *sw = getenv("CLFA_R2X13");   // tuning switch, read once: 0 = packed real size 32768 on k_fft_lds<14>
     p->r2x13 = sw ? atoi(sw) != 0 : true;
   }
+  if (!real && p->logn == 15 && getenv("CLFA_C2X14") && atoi(getenv("CLFA_C2X14"))) {   // tuning switch, read once
+    p->c2x14 = true;
+    h.clear();
+    auto w = [&](long k, long nn) { h.push_back(mk((float)cos(k * 2 * kPI / nn), -(float)sin(k * 2 * kPI / nn))); };
+    for (int j = 0; j < 16; j++)
+      for (int t = 0; t < 16; t++) w(j * t, 256);
+    for (int k = 0; k < 4; k++)
+      for (int j = 0; j < 256; j++) w(((1 << k) * j) & 4095, 4096);
+    for (int m = 1; m <= 3; m++)
+      for (int t = 0; t < 1024; t++) w(m * t, 16384);
+    for (int t = 0; t < 1024; t++) w(t, 32768);
+    if ((e = upload(p->half2, h.data(), sizeof(cpx) * h.size()))) return e;
+  }
   if (p->c2x13 || p->r2x13) {
     // the n = 8192 lane tables (as above) + the radix-2 step's lane constants W_16384^t
     h.clear();
@@ -660,7 +674,7 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (p->logn > kMaxLog) return "k_big_cols";
   if (p->blue_m) return "bluestein";
   if (p->rlds15 || p->r2x13) return "k_rfft_2x";
-  if (p->c2x13) return "k_cfft_2x13";
+  if (p->c2x13 || p->c2x14) return "k_cfft_2x";
   return (p->logn <= kLdsMaxLog || p->lds14) ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
 }
 
@@ -702,6 +716,12 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
     FftTables t2 = p->tabs;
     t2.half = (const cpx *)p->half2.p;
     HIP_TRY(launch_rfft_2x13(p->fwd, d, t2, batch, p->di, s));
+    return CLFA_SUCCESS;
+  }
+  if (p->c2x14 && batch * 4 > p->di.num_cus) {
+    FftTables t2 = p->tabs;
+    t2.half = (const cpx *)p->half2.p;
+    HIP_TRY(launch_cfft_2x14(p->fwd, scale, d, t2, batch, p->di, s));
     return CLFA_SUCCESS;
   }
   if (p->c2x13 && batch * 4 > p->di.num_cus) {   // (fewer transforms: spread over the four-step column / row kernels)

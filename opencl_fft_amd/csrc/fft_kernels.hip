@@ -582,25 +582,35 @@ hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch,
 // step in registers: Z[i] = A[i] + W_16384^i B[i], Z[i + 8192] = A[i] - W_16384^i B[i].  512 lanes, 71 KiB of LDS:
 // two workgroups share a CU and overlap each other's memory phases — the whole-transform-in-LDS forms (k_fft_lds<14>
 // with 1024 lanes, the persistent four-step kernel) put ONE workgroup on a CU, and its load, pass and store phases
-// follow one another.  W_16384^(tid + 512 e) = (lane constant W_16384^tid) x (compile-time W_32^e).
+// follow one another.  W_16384^(tid + 512 e) = (lane constant W_16384^tid) x (compile-time W_32^e).  (k_cfft_2x<13>.)
 // ---------------------------------------------------------------------------------
-template <bool FWD, bool SCALE>
-__global__ __launch_bounds__(512, 4) void k_cfft_2x13(cpx *__restrict__ data, const cpx *__restrict__ tab_g, long batch) {
-  using G = LdsGeom<13>;
-  constexpr int LOGN = 13, LOGE = 4, E = 16, T = 512, M = 8192;
+// (LOGC = 14: n = 32768 on two 16384-point runs, one 1024-lane workgroup per CU — measured against the persistent
+// four-step kernel before choosing)
+template <int LOGC, bool FWD, bool SCALE>
+__global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_cfft_2x(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
+                                                                 long batch) {
+  using G = LdsGeom<LOGC>;
+  constexpr int LOGN = LOGC, LOGE = 4, E = 16, M = 1 << LOGC, T = M / E;
   __shared__ cpx s_tab[kLane13Lds];
   __shared__ cpx s_x[G::PADN];
   const int tid = threadIdx.x;
   for (int i = tid; i < kLane13Lds; i += T) s_tab[i] = tab_g[i];
-  const cpx wl0 = tab_g[kLane13Lds + tid];    // W_8192^tid
-  const cpx h0 = tab_g[kLane13Size + tid];    // W_16384^tid (forward sign, like every table)
+  const cpx wl0 = tab_g[kLane13Lds + tid];                                     // W_M^tid
+  const cpx h0 = tab_g[(LOGC == 14 ? kLane14Size : kLane13Size) + tid];        // W_2M^tid (forward sign, like every table)
   cpx *xb = s_x;
   __syncthreads();
 #pragma unroll 1
   for (long b = blockIdx.x; b < batch; b += gridDim.x) {
     int t = tid;   // opaque per iteration: LDS / global offsets are recomputed, not kept live across the loop
     asm volatile("" : "+v"(t));
-    const LaneTab13 tab{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0};
+    const auto tab = [&]() {
+      if constexpr (LOGC == 14) {
+        const cpx wl1 = cmul(wl0, wl0);
+        return LaneTab14{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0, wl1, cmul(wl0, wl1)};
+      } else {
+        return LaneTab13{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0};
+      }
+    }();
     cpx *x = data + b * (long)(2 * M);
     cpx va[E], vb[E];
 #pragma unroll
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(512, 4) void k_cfft_2x13(cpx *__restrict__ data, co
     }
     pass_compute<LOGN, LOGE, 0, FWD>(va, t, tab);
     wg_passes_pair<LOGN, LOGE, 0, FWD, false>(va, vb, t, tab, xb);
-    // radix-2 step: position i = t + T e
+    // radix-2 step: position i = t + T e, W_2M^i = W_2M^t W_32^e
     constexpr float c32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
                                0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
                                0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
@@ -625,7 +635,7 @@ __global__ __launch_bounds__(512, 4) void k_cfft_2x13(cpx *__restrict__ data, co
     constexpr float inv = SCALE ? 1.0f / (float)(2 * M) : 1.0f;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-      const cpx w = e == 0 ? h0 : ctw<true>(h0, c32[e], s32[e]);   // W_16384^(t + 512 e), forward sign
+      const cpx w = e == 0 ? h0 : ctw<true>(h0, c32[e], s32[e]);   // W_2M^(t + T e), forward sign
       const cpx p = cmulc<!FWD>(vb[e], w);
       cpx o0 = cadd(va[e], p), o1 = csub(va[e], p);
       if constexpr (SCALE) {
@@ -639,16 +649,26 @@ __global__ __launch_bounds__(512, 4) void k_cfft_2x13(cpx *__restrict__ data, co
   }
 }
 
-hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
-                            hipStream_t s) {
+template <int LOGC>
+static hipError_t launch_cfft_2x_n(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
+                                   hipStream_t s) {
   if (batch <= 0) return hipSuccess;
-  const long cap = 2L * di.num_cus;   // two 512-lane workgroups per CU
+  constexpr int T = (1 << LOGC) / 16;
+  const long cap = (LOGC == 13 ? 2L : 1L) * di.num_cus;   // two 512-lane workgroups per CU, or one of 1024 lanes
   const int grid = (int)(batch < cap ? batch : cap);
-  if (fwd && scale) hipLaunchKernelGGL((k_cfft_2x13<true, true>), dim3(grid), dim3(512), 0, s, data, t.half, batch);
-  else if (fwd) hipLaunchKernelGGL((k_cfft_2x13<true, false>), dim3(grid), dim3(512), 0, s, data, t.half, batch);
-  else if (!scale) hipLaunchKernelGGL((k_cfft_2x13<false, false>), dim3(grid), dim3(512), 0, s, data, t.half, batch);
+  if (fwd && scale) hipLaunchKernelGGL((k_cfft_2x<LOGC, true, true>), dim3(grid), dim3(T), 0, s, data, t.half, batch);
+  else if (fwd) hipLaunchKernelGGL((k_cfft_2x<LOGC, true, false>), dim3(grid), dim3(T), 0, s, data, t.half, batch);
+  else if (!scale) hipLaunchKernelGGL((k_cfft_2x<LOGC, false, false>), dim3(grid), dim3(T), 0, s, data, t.half, batch);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
+                            hipStream_t s) {
+  return launch_cfft_2x_n<13>(fwd, scale, data, t, batch, di, s);
+}
+hipError_t launch_cfft_2x14(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
+                            hipStream_t s) {
+  return launch_cfft_2x_n<14>(fwd, scale, data, t, batch, di, s);
 }
 
 // ---------------------------------------------------------------------------------

@@ -50,6 +50,10 @@ hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch,
 // (kLane13Size) followed by W_16384^t, t < 512
 hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
                             hipStream_t s);
+// ... and n = 32768 as two 16384-point runs (t.half = the n = 16384 lane tables, kLane14Size, followed by W_32768^t,
+// t < 1024): experiment behind CLFA_C2X14=1
+hipError_t launch_cfft_2x14(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
+                            hipStream_t s);
 
 // four-step FFT, n = 2^logn in (2^kLdsMaxLog, 2^kMaxLog]; scratch = fourstep_grid() * n complex
 // (n = 65536 with more than a few transforms runs the resident kernel below and uses the first
