@@ -271,6 +271,7 @@ struct clfa_fft {
   bool c2x13 = false;    // complex n = 16384: k_cfft_2x13 (two 8192-point runs per transform, two workgroups per CU)
   bool r2x13 = false;    // packed real size 32768: k_rfft_2x<13> (the same, with the pair maps in registers)
   bool c2x14 = false;    // complex n = 32768 on two 16384-point runs (experiment, CLFA_C2X14=1)
+  bool r2x11 = false;    // packed real size 8192: k_rfft_2x<11, 3> (two 2048-point runs, eight points per lane)
   DevBuf half2;          // ... their tables: the n = 8192 lane tables + W_16384^t, t < 512
   long spread_below = 0; // real sizes 32768 / 65536: batches up to this run the four-step pair + pack kernel instead
   // any other length (extension): Bluestein around two power-of-two plans of length blue_m
@@ -596,6 +597,16 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     for (int t = 0; t < 1024; t++) w(t, 32768);
     if ((e = upload(p->half2, h.data(), sizeof(cpx) * h.size()))) return e;
   }
+  if (real && p->logn == 12) {
+    // tuning switch, read once: 1 = packed real size 8192 on two 2048-point runs (measured 4 % slower than k_fft_lds<12>
+    // with its pair exchange through LDS: 4.70 against 4.91 TB/s, so not the default)
+    const char *sw = getenv("CLFA_R2X11");
+    p->r2x11 = sw ? atoi(sw) != 0 : false;
+    if (p->r2x11) {
+      fill_twiddle(h, 1024, 2048, 1, -1.f);   // the half table of the 2048-point runs
+      if ((e = upload(p->half2, h.data(), sizeof(cpx) * 1024))) return e;
+    }
+  }
   if (p->c2x13 || p->r2x13) {
     // the n = 8192 lane tables (as above) + the radix-2 step's lane constants W_16384^t
     h.clear();
@@ -673,7 +684,7 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
   if (p->logn > kMaxLog) return "k_big_cols";
   if (p->blue_m) return "bluestein";
-  if (p->rlds15 || p->r2x13) return "k_rfft_2x";
+  if (p->rlds15 || p->r2x13 || p->r2x11) return "k_rfft_2x";
   if (p->c2x13 || p->c2x14) return "k_cfft_2x";
   return (p->logn <= kLdsMaxLog || p->lds14) ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
 }
@@ -710,6 +721,12 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   const bool spread = p->real && batch <= p->spread_below;   // a few transforms: one workgroup each would be slower
   if (p->rlds15 && !spread) {
     HIP_TRY(launch_rfft_lds15(p->fwd, d, p->tabs, batch, p->di, s));
+    return CLFA_SUCCESS;
+  }
+  if (p->r2x11) {
+    FftTables t2 = p->tabs;
+    t2.half = (const cpx *)p->half2.p;
+    HIP_TRY(launch_rfft_2x11(p->fwd, d, t2, batch, p->di, s));
     return CLFA_SUCCESS;
   }
   if (p->r2x13 && !spread) {

@@ -747,8 +747,7 @@ CLFA_HD void pass_last_paired(cpx (&v)[1 << LOGE], int tid, const Tab &tab, cons
         v[u + U / 2 + U * t] = xb[lds_pad(jp + NB * t)];
       }
     }
-    if constexpr (!is_lane_tab<Tab>::value) {
-      static_assert(std::is_same<Mid, NoMid>::value, "mid hook: lane-table twiddles only (they follow the whole gather)");
+    if constexpr (!is_lane_tab<Tab>::value) {   // (table twiddles go with the gather; mid() then follows both)
 #pragma unroll
       for (int t = 1; t < R; t++) {
         v[u + U * t] = cmul_tw<LOGN, FWD>(v[u + U * t], tab, j * t);
@@ -913,10 +912,13 @@ template <bool FWD, int S> CLFA_HD cpx pair_tw13(cpx c0, int u, int q, int lane)
   if (u == 0 && lane == 0) w = S == 0 ? mk(kC8, FWD ? -kC8 : kC8) : mk(kC16, FWD ? -kS16 : kS16);   // W_P^2048
   return w;
 }
+// (LOGC = 11 with EIGHT points per lane — passes 8 x 8 x 8 x 4, 256 lanes — has the pair structure of LOGC = 14 scaled by
+// 1/8: four pairs per u, NB = M / 4, and only u = 0; every constant of pair_tw14 is a ratio of NB or of the lane-0
+// positions to P, so it applies unchanged)
 template <int LOGC, bool FWD, int S> CLFA_HD cpx pair_tw2x(cpx c0, int u, int q, int lane) {
-  static_assert(LOGC == 13 || LOGC == 14, "sub-transforms of 8192 or 16384 points");
-  if constexpr (LOGC == 14) return pair_tw14<FWD, S>(c0, u, q, lane);
-  else return pair_tw13<FWD, S>(c0, u, q, lane);
+  static_assert(LOGC == 11 || LOGC == 13 || LOGC == 14, "sub-transforms of 2048, 8192 or 16384 points");
+  if constexpr (LOGC == 13) return pair_tw13<FWD, S>(c0, u, q, lane);
+  else return pair_tw14<FWD, S>(c0, u, q, lane);
 }
 constexpr int kM15 = 16384;
 // forward: slot (u, q) of lane `lane`: A[i], A[M - i], B[i], B[M - i] (for i = 0: A[0], A[M / 2], ...) ->

@@ -441,12 +441,13 @@ struct R15Off {
 };
 // LOGC: the sub-transforms' length (14: real size 65536, T = 1024 lanes, four pairs per u; 13: real size 32768,
 // T = 512 lanes, two pairs per u — pair_index<13, 4>: q = 0 -> i = j, 1 -> 4096 - j)
-template <int LOGC> __device__ __forceinline__ R15Off rfft2x_off(const XferBuf &b, int t, int u, int q, int which) {
-  constexpr int M = 1 << LOGC, NB = 4096, T = M / 16;
-  if (u == 0) return R15Off{rfft2x_pos<LOGC>(pair_index<LOGC, 4>(t, 0, q), which) * 8, 0};
+template <int LOGC, int LOGE> __device__ __forceinline__ R15Off rfft2x_off(const XferBuf &b, int t, int u, int q, int which) {
+  constexpr int LOGR = pass_rem_logr(LOGC, LOGE), R = 1 << LOGR, M = 1 << LOGC, NB = M >> LOGR, T = M >> LOGE;
+  static_assert(R == 2 || R == 4, "two or four pairs per u");
+  if (u == 0) return R15Off{rfft2x_pos<LOGC>(pair_index<LOGC, LOGE>(t, 0, q), which) * 8, 0};
   // i = +j + ci or -j + ci;  position = which 0: i, 1: 2M - i, 2: M - i, 3: M + i
-  const bool ineg = LOGC == 14 ? q >= 2 : q >= 1;
-  const int ci = LOGC == 14 ? (q == 0 ? 0 : q == 1 ? NB : q == 2 ? 2 * NB : NB) : (q == 0 ? 0 : NB);
+  const bool ineg = q >= R / 2;
+  const int ci = R == 4 ? (q == 0 ? 0 : q == 1 ? NB : q == 2 ? 2 * NB : NB) : (q == 0 ? 0 : NB);
   const bool neg = (which == 1 || which == 2) ? !ineg : ineg;                       // sign of j in the position
   const int c = which == 0 ? ci : which == 1 ? 2 * M - ci : which == 2 ? M - ci : M + ci;   // position = c +- j
   return neg ? R15Off{b.vd, (c - u * T - T) * 8} : R15Off{b.va, (c + u * T) * 8};
@@ -459,18 +460,21 @@ __device__ __forceinline__ void st_nt16(cpx *p, f4v v) {
 // k_rfft_2x<14>: real size 65536, one 1024-lane workgroup per CU (formerly k_rfft_lds15);
 // k_rfft_2x<13>: real size 32768, 512 lanes and 71 KiB of LDS — TWO workgroups per CU, which overlap each other's
 // memory phases (k_fft_lds<14> with its pair maps puts one 1024-lane workgroup on a CU)
-template <int LOGC, bool FWD, bool SCALE>
-__global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_rfft_2x(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
-                                                                 const cpx *__restrict__ w2_g, long batch) {
-  using G = LdsGeom<LOGC>;
-  constexpr int LOGN = LOGC, LOGE = 4, E = 16, M = 1 << LOGC, T = M / E, R = 1 << pass_rem_logr(LOGC, LOGE);
-  __shared__ cpx s_tab[kLane13Lds];
-  __shared__ cpx s_x[G::PADN];
+// k_rfft_2x<11, 3>: real size 8192 on two 2048-point runs with EIGHT points per lane (passes 8 x 8 x 8 x 4: the remainder
+// pass pairs, which no 16-point-per-lane form of a 4096-point transform does), 256 lanes, the half table in LDS
+template <int LOGC, bool FWD, bool SCALE, int LOGE = 4>
+__global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
+                                                                    const cpx *__restrict__ w2_g, long batch) {
+  constexpr int LOGN = LOGC, E = 1 << LOGE, M = 1 << LOGC, T = M / E, R = 1 << pass_rem_logr(LOGC, LOGE);
+  constexpr bool LANE = kLdsTwoLevel(LOGC);   // lane-addressed tables (8192 / 16384 points) or the half table W_M^k
+  constexpr int NTAB = LANE ? kLane13Lds : M / 2;
+  __shared__ cpx s_tab[NTAB];
+  __shared__ cpx s_x[lds_padded_size(M)];
   const int tid = threadIdx.x;
-  for (int i = tid; i < kLane13Lds; i += T) s_tab[i] = tab_g[i];
+  for (int i = tid; i < NTAB; i += T) s_tab[i] = tab_g[i];
   // lane constants kept across the batch loop: W_M^tid and W_4M^tid only (4 VGPRs; the kernel runs under the 128-VGPR
   // cap) — W_M^(2 tid), ^(3 tid) and W_2M^tid are their products
-  const cpx wl0 = tab_g[kLane13Lds + tid];
+  const cpx wl0 = LANE ? tab_g[kLane13Lds + tid] : mk(1.f, 0.f);
   const cpx h0 = w2_g[tid];   // W_4M^tid (the plan's sign)
   cpx *xb = s_x;
   __syncthreads();
@@ -482,8 +486,10 @@ __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_rfft_2x(cpx *__restrict
       if constexpr (LOGC == 14) {
         const cpx wl1 = cmul(wl0, wl0);
         return LaneTab14{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0, wl1, cmul(wl0, wl1)};
-      } else {
+      } else if constexpr (LOGC == 13) {
         return LaneTab13{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0};
+      } else {
+        return static_cast<const cpx *>(s_tab);
       }
     }();
     const cpx g0 = cmul(h0, h0);   // W_2M^tid
@@ -530,7 +536,7 @@ __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_rfft_2x(cpx *__restrict
       for (int k = 0; k < E / 2; k++)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-          const R15Off o = rfft2x_off<LOGC>(xo, t, k / R, k % R, w);
+          const R15Off o = rfft2x_off<LOGC, LOGE>(xo, t, k / R, k % R, w);
           raw[4 * k + w] = ld_buf<CLFA_NT_LD_R15 != 0>(xo, o.v, o.s);
         }
 #pragma unroll
@@ -564,6 +570,29 @@ hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch
   const int grid = (int)(batch < di.num_cus ? batch : di.num_cus);   // one 1024-lane workgroup per CU
   if (fwd) hipLaunchKernelGGL((k_rfft_2x<14, true, true>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
   else hipLaunchKernelGGL((k_rfft_2x<14, false, false>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
+  return hipGetLastError();
+}
+// real size 8192: t.half = the half table of 2048 points (1024 entries), t.w2 = the plan's r2c table (4096 entries)
+hipError_t launch_rfft_2x11(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  // persistent 256-lane workgroups, 25 KiB of LDS each: as many as are resident at once (a grid beyond that would run
+  // its last workgroups after the others have finished their whole share)
+  static int per_cu[2] = {0, 0};
+  int &nb = per_cu[fwd ? 1 : 0];
+  if (nb == 0) {
+    int q = 0;
+    const hipError_t e = fwd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_rfft_2x<11, true, true, 3>, 256, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_rfft_2x<11, false, false, 3>, 256, 0);
+    if (e != hipSuccess || q < 1) {
+      (void)hipGetLastError();
+      q = 4;
+    }
+    nb = q;
+  }
+  const long cap = (long)nb * di.num_cus;
+  const int grid = (int)(batch < cap ? batch : cap);
+  if (fwd) hipLaunchKernelGGL((k_rfft_2x<11, true, true, 3>), dim3(grid), dim3(256), 0, s, data, t.half, t.w2, batch);
+  else hipLaunchKernelGGL((k_rfft_2x<11, false, false, 3>), dim3(grid), dim3(256), 0, s, data, t.half, t.w2, batch);
   return hipGetLastError();
 }
 // real size 32768: t.half = the n = 8192 lane tables (kLane13Size), t.w2 = the plan's r2c table (16384 entries)

@@ -46,6 +46,8 @@ hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch
 // packed real size 32768 the same way on two 8192-point runs (two 512-lane workgroups per CU); t.half = the n = 8192
 // lane tables (kLane13Size), t.w2 = the plan's r2c table
 hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
+// packed real size 8192 on two 2048-point runs, eight points per lane; t.half = the half table of 2048 points
+hipError_t launch_rfft_2x11(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
 // complex n = 16384 as two 8192-point runs + a radix-2 step in registers; t.half = the n = 8192 lane tables
 // (kLane13Size) followed by W_16384^t, t < 512
 hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,

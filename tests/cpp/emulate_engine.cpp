@@ -382,10 +382,13 @@ template <int LOGN> static int lane_tables() {
 }
 
 // ---- packed real sizes 32768 / 65536 on two 8192- / 16384-point sub-transforms (rfft2x_fwd_slot / rfft2x_inv_slot) -----
-template <int LOGN> static int rfft2x() {
-  constexpr int LOGE = 4, M = 1 << LOGN, n = 2 * M, E = 16, T = M / E, R = 1 << pass_rem_logr(LOGN, LOGE), U = E / R;
+// (LOGN = 13, 14: lane tables, 16 points per lane; LOGN = 11 with 8 points per lane: the half table)
+template <int LOGN, int LOGE = 4> static int rfft2x() {
+  constexpr int M = 1 << LOGN, n = 2 * M, E = 1 << LOGE, T = M / E, R = 1 << pass_rem_logr(LOGN, LOGE), U = E / R, NP = E / 2;
+  constexpr bool LANE = LOGN >= 13;
   std::vector<cpx> blob, z(n), half(n / 2), w2f(n), w2i(n), lds(lds_padded_size(n));
-  auto tabs = make_lane_tabs<LOGN>(blob);
+  auto tabs = make_lane_tabs<LANE ? LOGN : 13>(blob);
+  std::vector<cpx> halfc(M / 2);   // the sub-transforms' half table (LOGN < 13)
   unsigned s = 31337u;
   for (auto &c : z) {
     s = s * 1664525u + 1013904223u; c.x = (float)(s >> 8) / 8388608.0f - 1.0f;
@@ -393,6 +396,7 @@ template <int LOGN> static int rfft2x() {
   }
   const double PI = 3.141592653589793;
   for (int i = 0; i < n / 2; i++) half[i] = mk((float)cos(i * 2 * PI / n), -(float)sin(i * 2 * PI / n));
+  for (int i = 0; i < M / 2; i++) halfc[i] = mk((float)cos(i * 2 * PI / M), -(float)sin(i * 2 * PI / M));
   for (int i = 0; i < n; i++) {
     w2f[i] = mk((float)cos(i * PI / n), -(float)sin(i * PI / n));
     w2i[i] = mk((float)cos(i * PI / n), (float)sin(i * PI / n));
@@ -417,19 +421,24 @@ template <int LOGN> static int rfft2x() {
       ra[tid * E + e] = z[2 * (tid + T * e)];
       rb[tid * E + e] = z[2 * (tid + T * e) + 1];
     }
-  run_lane<LOGN, 0, true, true>(ra, tabs, lds);
-  run_lane<LOGN, 0, true, true>(rb, tabs, lds);
+  if constexpr (LANE) {
+    run_lane<LOGN, 0, true, true>(ra, tabs, lds);
+    run_lane<LOGN, 0, true, true>(rb, tabs, lds);
+  } else {
+    run_pairlast<LOGN, LOGE, 0>(ra, halfc, lds);
+    run_pairlast<LOGN, LOGE, 0>(rb, halfc, lds);
+  }
   std::vector<int> seen(n, 0);
   for (int tid = 0; tid < T; tid++) {
-    cpx ai[8], aj[8], bi[8], bj[8];
-    int ii[8];
+    cpx ai[NP], aj[NP], bi[NP], bj[NP];
+    int ii[NP];
     pairs_visit<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&ra[tid * E]), tid, [&](int k, int i, cpx ci, cpx cj) {
       ai[k] = cscale(ci, 1.0f / (float)n); aj[k] = cscale(cj, 1.0f / (float)n); ii[k] = i;
     });
     pairs_visit<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&rb[tid * E]), tid, [&](int k, int i, cpx ci, cpx cj) {
       (void)i; bi[k] = cscale(ci, 1.0f / (float)n); bj[k] = cscale(cj, 1.0f / (float)n);
     });
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < NP; k++)
       rfft2x_fwd_slot<LOGN>(tid, k / R, k % R, ii[k], ai[k], aj[k], bi[k], bj[k], w2f[2 * tid], w2f[tid],
                       [&](int pos, cpx v) { got[pos] = v; seen[pos]++; });
   }
@@ -455,7 +464,7 @@ template <int LOGN> static int rfft2x() {
   }
   std::fill(seen.begin(), seen.end(), 0);
   std::vector<cpx> oa(M / 2 * 1), dummy;
-  std::vector<cpx> OA(T * 8), PA(T * 8), OB(T * 8), PB(T * 8);
+  std::vector<cpx> OA(T * NP), PA(T * NP), OB(T * NP), PB(T * NP);
   for (int tid = 0; tid < T; tid++)
     for (int u = 0; u < U / 2; u++)
       for (int q = 0; q < R; q++) {
@@ -466,20 +475,24 @@ template <int LOGN> static int rfft2x() {
           seen[pos]++;
           in[w] = z[pos];
         }
-        rfft2x_inv_slot<LOGN>(tid, u, q, i, w2i[2 * tid], w2i[tid], in[0], in[1], in[2], in[3], OA[tid * 8 + k], PA[tid * 8 + k],
-                        OB[tid * 8 + k], PB[tid * 8 + k]);
+        rfft2x_inv_slot<LOGN>(tid, u, q, i, w2i[2 * tid], w2i[tid], in[0], in[1], in[2], in[3], OA[tid * NP + k], PA[tid * NP + k],
+                        OB[tid * NP + k], PB[tid * NP + k]);
       }
   for (int i = 0; i < n; i++) if (seen[i] != 1) bad |= 4;
   for (int half_ = 0; half_ < 2; half_++) {
     std::vector<cpx> &O = half_ ? OB : OA, &P = half_ ? PB : PA;
     std::vector<cpx> r(M);
-    for (int tid = 0; tid < T; tid++)
-      pass_first_paired<LOGN, LOGE, false>(*reinterpret_cast<cpx(*)[E]>(&r[tid * E]), tid,
-                                           *reinterpret_cast<const cpx(*)[8]>(&O[tid * 8]),
-                                           *reinterpret_cast<const cpx(*)[8]>(&P[tid * 8]), tabs[tid]);
+    for (int tid = 0; tid < T; tid++) {
+      auto &rv = *reinterpret_cast<cpx(*)[E]>(&r[tid * E]);
+      const auto &ov = *reinterpret_cast<const cpx(*)[NP]>(&O[tid * NP]);
+      const auto &pv = *reinterpret_cast<const cpx(*)[NP]>(&P[tid * NP]);
+      if constexpr (LANE) pass_first_paired<LOGN, LOGE, false>(rv, tid, ov, pv, tabs[tid]);
+      else pass_first_paired<LOGN, LOGE, false>(rv, tid, ov, pv, halfc);
+    }
     for (int tid = 0; tid < T; tid++)
       pass_first_paired_scatter<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&r[tid * E]), tid, lds.data());
-    run_lane_dif_inv<LOGN, pass_last_logns(LOGN, LOGE) - LOGE>(r, tabs, lds);
+    if constexpr (LANE) run_lane_dif_inv<LOGN, pass_last_logns(LOGN, LOGE) - LOGE>(r, tabs, lds);
+    else run_dif_inv<LOGN, LOGE, pass_last_logns(LOGN, LOGE) - LOGE>(r, halfc, lds);
     for (int tid = 0; tid < T; tid++)
       for (int e = 0; e < E; e++) goti[2 * (tid + T * e) + half_] = r[tid * E + e];
   }
@@ -506,7 +519,7 @@ int main() {
             paired<13, 4>() | paired<4, 3>() | paired<5, 3>() | paired<7, 3>();
   g_fail |= paired<14, 4>();
   g_fail |= lane_tables<13>() | lane_tables<14>();
-  g_fail |= rfft2x<14>() | rfft2x<13>();
+  g_fail |= rfft2x<14>() | rfft2x<13>() | rfft2x<11, 3>();
   puts(g_fail ? "FAIL" : "OK");
   return g_fail;
 }

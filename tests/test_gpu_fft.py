@@ -180,20 +180,24 @@ def test_cfft_batched_kernels_vs_reference_vectors(n):
         assert np.array_equal(y.view(np.uint32), np.tile(y[0], (batch, 1)).view(np.uint32)), "transforms of one batch differ"
 
 
-@pytest.mark.parametrize("size,kernel", [(32768, "k_rfft_2x"), (32768, "k_fft_lds"), (65536, "k_rfft_2x"), (131072, None)])
+@pytest.mark.parametrize("size,kernel", [(8192, "k_rfft_2x"), (8192, "k_fft_lds"), (32768, "k_rfft_2x"), (32768, "k_fft_lds"),
+                                         (65536, "k_rfft_2x"), (131072, None)])
 def test_rfft_batched_kernels_vs_reference_vectors(size, kernel):
     """Clrfft::transform (cl_fft.cpp:267-296) vectors against the one-pass real kernels: more than 32 transforms select
-    k_rfft_2x (two 8192-point runs for size 32768, two 16384-point runs for size 65536; size 32768 also on k_fft_lds<14>,
-    still in the library behind its plan-time switch) instead of the spread path a single transform takes; every
+    k_rfft_2x (two 2048- / 8192- / 16384-point runs for sizes 8192 / 32768 / 65536; sizes 8192 and 32768 also on
+    k_fft_lds<12> / <14>, still in the library behind their plan-time switches) instead of the spread path a single transform takes; every
     transform of the batch against the reference's forward, round-trip and arbitrary-spectrum inverse vectors, bin M/2
     (the reference's never-conjugated self-paired bin, cl_fft.cpp:278) included."""
     batch, m = 70, size // 2
-    if kernel == "k_fft_lds":
+    if size == 8192 and kernel == "k_rfft_2x":
+        os.environ["CLFA_R2X11"] = "1"   # (two 2048-point runs: measured slower than k_fft_lds<12>, not the default)
+    if size == 32768 and kernel == "k_fft_lds":
         os.environ["CLFA_R2X13"] = "0"
     try:
         f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
     finally:
         os.environ.pop("CLFA_R2X13", None)
+        os.environ.pop("CLFA_R2X11", None)
     if kernel is not None:
         assert f.kernel_name() == kernel and i.kernel_name() == kernel
     x = np.tile(util.lcg_sym(12345, size), (batch, 1))
