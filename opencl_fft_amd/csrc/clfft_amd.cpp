@@ -267,8 +267,8 @@ struct clfa_fft {
   // n = 16384 on the one-workgroup-per-CU LDS kernel (packed real size 32768 always: the pair maps are fused
   // there; complex plans when CLFA_LDS14 says so — resolved at creation)
   bool lds14 = false;
-  bool rlds15 = false;   // packed real size 65536: k_rfft_lds15 (two 16384-point runs per transform, one HBM pass)
-  bool c2x13 = false;    // complex n = 16384: k_cfft_2x13 (two 8192-point runs per transform, two workgroups per CU)
+  bool rlds15 = false;   // packed real size 65536: k_rfft_2x<14> (two 16384-point runs per transform, one HBM pass)
+  bool c2x13 = false;    // complex n = 16384: k_cfft_2x<13> (two 8192-point runs per transform, two workgroups per CU)
   bool r2x13 = false;    // packed real size 32768: k_rfft_2x<13> (the same, with the pair maps in registers)
   bool c2x14 = false;    // complex n = 32768 on two 16384-point runs (experiment, CLFA_C2X14=1)
   bool r2x11 = false;    // packed real size 8192: k_rfft_2x<11, 3> (two 2048-point runs, eight points per lane)

@@ -920,7 +920,6 @@ template <int LOGC, bool FWD, int S> CLFA_HD cpx pair_tw2x(cpx c0, int u, int q,
   if constexpr (LOGC == 13) return pair_tw13<FWD, S>(c0, u, q, lane);
   else return pair_tw14<FWD, S>(c0, u, q, lane);
 }
-constexpr int kM15 = 16384;
 // forward: slot (u, q) of lane `lane`: A[i], A[M - i], B[i], B[M - i] (for i = 0: A[0], A[M / 2], ...) ->
 // st(position, packed spectrum value) x 4.  g0 = W_2M^lane, h0 = W_4M^lane (the r2c table's entries 2 lane, lane).
 // M = 2^LOGC is the length of the sub-transforms.

@@ -78,7 +78,7 @@ template <int LOGN> __device__ __forceinline__ XferBuf xfer_buf(const cpx *x, in
 // 0.2012 / 0.2027 with one of them; sizes 8192 and 32768 within 1 %.  (The complex kernels lose 2-9 % with plain
 // loads and 3-8 % with plain stores: they keep non-temporal both ways — profiles/ab_cache_policy_r03.txt.)
 // The same holds for the persistent four-step kernel (n = 2^14, 2^15: 4.80 -> 4.83, 4.82 -> 4.93 TB/s) and for packed
-// real size 65536 (k_rfft_lds15: 3.80 -> 3.96 TB/s): plain loads, non-temporal stores.
+// real size 65536 (k_rfft_2x<14>: 3.80 -> 3.96 TB/s): plain loads, non-temporal stores.
 #ifndef CLFA_NT_LD_4STEP
 #define CLFA_NT_LD_4STEP 0
 #endif
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
 // n = 2 M, M = 16384: the even and odd complex samples z[2j], z[2j+1] — one 16-byte access per lane — go
 // through the 16384-point pass chain one after the other (same 1024 lanes, same exchange buffer); the
 // radix-2 step that joins them and the reference's pair map (cl_fft.cpp:178-205) meet in registers
-// (fft_device.hpp, rfft15_fwd_slot / rfft15_inv_slot): one HBM pass, where the four-step kernel plus the
+// (fft_device.hpp, rfft2x_fwd_slot / rfft2x_inv_slot): one HBM pass, where the four-step kernel plus the
 // stand-alone pack kernel took two.  The inverse runs the transposed network.
 __device__ __forceinline__ f4v ld_nt16(const cpx *p) {
   return CLFA_NT_LD_R15 ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)) : *reinterpret_cast<const f4v *>(p);
@@ -430,12 +430,12 @@ __device__ __forceinline__ cpx ld_r15(const cpx *p) {
   if (CLFA_NT_LD_R15) return ld_nt(p);
   return *p;
 }
-// Byte offsets (vector part, scalar part) of the four packed bins of slot (u, q) of lane t (rfft15_pos(i, which),
+// Byte offsets (vector part, scalar part) of the four packed bins of slot (u, q) of lane t (rfft2x_pos(i, which),
 // i = pair_index<14, 4>(t, u, q)): every one of them is C + j or C - j, j = t + 1024 u, so the lane part is one of TWO
 // VGPRs (t * 8, (1024 - t) * 8) and the rest scalar.  With flat addresses each of the 32 accesses of a lane carried
 // its own 64-bit address pair — hipcc then issued the inverse kernel's loads four at a time, each group behind a
 // full s_waitcnt vmcnt(0): eight exposed memory latencies per transform.  The u = 0 slots carry lane 0's exceptions
-// (pair_index, rfft15_pos) in the vector part.
+// (pair_index, rfft2x_pos) in the vector part.
 struct R15Off {
   int v, s;
 };

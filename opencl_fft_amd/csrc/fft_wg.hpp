@@ -40,7 +40,7 @@ __device__ __forceinline__ void wg_passes_dif_after(cpx (&v)[1 << LOGE], int t, 
 }
 
 // TWO independent transforms through ONE exchange buffer, staggered (packed real size 65536: the even and the odd
-// half of a transform, k_rfft_lds15): while one transform's values are on their way through LDS the other's pass is
+// half of a transform, k_rfft_2x; two runs of a complex transform, k_cfft_2x): while one transform's values are on their way through LDS the other's pass is
 // computed.  Run one after the other, every wave of the workgroup does the same thing at the same time — all of them
 // compute, then all of them wait for their scattered writes to drain (16 ds_write_b64 per lane move at a third of the
 // LDS read rate), then all of them gather — and the chains, not the memory, bound the kernel.
