@@ -220,6 +220,40 @@ def test_dconv_device_resident_blocks_vs_oracle(irsize, vsize, blocks, tv):
     assert d.process_device(dout[0], dout[0]) == -30   # out must not be an input
 
 
+def test_dconv_handoff_under_load():
+    """k_dconv_block's hand-over of the tap chunks' partial sums (agent-scope stores, arrival counter per output block,
+    the last workgroup adds in fixed order) under UNEVEN load: the same blocks once on an idle GPU and once while another
+    stream keeps every CU busy with large transforms — the two runs must agree bit for bit."""
+    import torch
+    blocks = 120
+    for irsize, vsize, tv in ((96000, 64, False), (70000, 256, True), (300000, 16, False)):
+        g = torch.Generator(device="cuda").manual_seed(irsize + vsize)
+        ir = ((torch.rand(irsize, generator=g, device="cuda") - 0.5) / irsize ** 0.5).cpu().numpy()
+        x1 = torch.rand((blocks, vsize), generator=g, device="cuda") * 2 - 1
+        x2 = (torch.rand((blocks, vsize), generator=g, device="cuda") - 0.5) / irsize ** 0.5
+        big = torch.rand((512, 65536, 2), device="cuda") * 2 - 1
+        f, i = fa.Clcfft(0, 65536, True), fa.Clcfft(0, 65536, False)
+        outs = []
+        for loaded in (False, True):
+            d = fa.Cldconv(0, irsize, vsize)
+            assert d.get_cl_err() == 0 and d.push_ir(ir) == 0
+            y = torch.empty((blocks, vsize), device="cuda")
+            torch.cuda.synchronize()
+            sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+            for b in range(blocks):
+                if loaded and b % 4 == 0:
+                    assert (f if (b // 4) % 2 == 0 else i).exec_device(big, 512, sb.cuda_stream) == 0
+                assert d.process_device(y[b], x1[b], x2[b] if tv else None, sa.cuda_stream) == 0
+            torch.cuda.synchronize()
+            outs.append(y)
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (irsize, vsize, tv)
+        o = oracle.Dconv(irsize, vsize)
+        o.push_ir(ir)
+        xs1, xs2 = x1.cpu().numpy(), x2.cpu().numpy()
+        want = np.stack([o.convolution(xs1[b], xs2[b]) if tv else o.convolution(xs1[b]) for b in range(6)])
+        assert_parity(outs[1][:6].cpu().numpy(), want, tol=max(2e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24), what="first blocks vs oracle")
+
+
 def test_dconv_time_varying_vs_oracle():
     irsize, vsize, blocks = 32, 8, 12
     s = util.lcg_half(5, 2 * vsize * blocks)
