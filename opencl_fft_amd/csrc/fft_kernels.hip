@@ -1348,6 +1348,8 @@ int big_split(int logn, BigGeom *g) {
     g->logn1 = logn - g->logn2;
   }
   g->loglo = 12;
+  const char *sw = getenv("CLFA_BIG2X");   // tuning switch, read once (at plan creation): 0 = one-run 1024-point blocks
+  g->two_run = sw ? atoi(sw) != 0 : true;
   return 0;
 }
 
@@ -1467,6 +1469,45 @@ __global__ __launch_bounds__(1 << LOGN1) void k_big2_cols(const cpx *__restrict_
   }
 }
 
+// N1 = 1024 in the two-run form of k_cfft_2x: the block's 16 columns x 1024 rows as two
+// 512-point runs per column (even / odd rows) through ONE 64 KiB exchange buffer and a radix-2 step in registers —
+// 512 lanes and half the LDS, so two workgroups share a CU where the one-run form (128 KiB) leaves one
+template <bool FWD>
+__global__ __launch_bounds__(512, 4) void k_big2_cols_2x(const cpx *__restrict__ data, cpx *__restrict__ scratch,
+                                                         const cpx *__restrict__ tabs_g, int logn2, int loglo) {
+  constexpr int LOGC = 9, M = 1 << LOGC, TC = M / 16;   // 512-point runs, 32 lanes per column
+  __shared__ cpx s_tabh[M / 2];   // W_512^k
+  __shared__ cpx s_tabj[M];       // W_1024^k, k < 512 (the radix-2 step)
+  __shared__ cpx s_x[M * 16];
+  const int tid = threadIdx.x;
+  s_tabj[tid] = tabs_g[tid];
+  if (tid < M / 2) s_tabh[tid] = tabs_g[2 * tid];
+  const cpx *tlo = tabs_g + M, *thi = tlo + (1 << loglo);
+  const int col = tid % 16, tf = tid / 16;
+  const int n2 = blockIdx.x * 16 + col;
+  const long base = ((long)blockIdx.y << (LOGC + 1 + logn2)) + n2;
+  cpx va[16], vb[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    va[e] = ld_nt(data + base + ((long)(2 * (tf + TC * e)) << logn2));
+    vb[e] = ld_nt(data + base + ((long)(2 * (tf + TC * e) + 1) << logn2));
+  }
+  __syncthreads();
+  col_passes<LOGC, 0, FWD>(va, tf, s_tabh, s_x, col);
+  __syncthreads();
+  col_passes<LOGC, 0, FWD>(vb, tf, s_tabh, s_x, col);
+  const int mlo = (1 << loglo) - 1;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int k = tf + TC * e;
+    const cpx p = cmulc<!FWD>(vb[e], s_tabj[k]);
+    const cpx o0 = cadd(va[e], p), o1 = csub(va[e], p);
+    const int ex0 = n2 * k, ex1 = n2 * (k + M);  // < n <= 2^20
+    scratch[base + ((long)k << logn2)] = cmulc<!FWD>(o0, cmul(tlo[ex0 & mlo], thi[ex0 >> loglo]));
+    scratch[base + ((long)(k + M) << logn2)] = cmulc<!FWD>(o1, cmul(tlo[ex1 & mlo], thi[ex1 >> loglo]));
+  }
+}
+
 // all passes but the last with the lanes of a row adjacent (tf fast); the last one with the 16 rows on
 // the fast lane index, so that the transposed store is 128-byte segments
 template <int LOGN2, int LOGNS, bool FWD>
@@ -1515,6 +1556,50 @@ __global__ __launch_bounds__(1 << LOGN2) void k_big2_rows(const cpx *__restrict_
   }
 }
 
+// N2 = 1024 in the two-run form: 16 rows x 1024 points as two 512-point runs per row (one 16-byte load per lane brings
+// an even and an odd sample), the last pass with the rows on the fast lane index as above, radix-2 step in registers
+template <bool FWD, bool SCALE>
+__global__ __launch_bounds__(512, 4) void k_big2_rows_2x(const cpx *__restrict__ scratch, cpx *__restrict__ data,
+                                                         const cpx *__restrict__ tab_g, int logn1, float inv_n) {
+  constexpr int LOGC = 9, M = 1 << LOGC, TC = M / 16, S2 = lds_padded_size(M) | 1;
+  __shared__ cpx s_tabh[M / 2];   // W_512^k
+  __shared__ cpx s_tabj[M];       // W_1024^k, k < 512
+  __shared__ cpx s_x[16 * S2];
+  const int l = threadIdx.x;
+  s_tabj[l] = tab_g[l];
+  if (l < M / 2) s_tabh[l] = tab_g[2 * l];
+  const long tbase = (long)blockIdx.y << (LOGC + 1 + logn1);
+  cpx va[16], vb[16];
+  {
+    const int tf = l % TC, row = l / TC;
+    const cpx *p = scratch + tbase + ((long)(blockIdx.x * 16 + row) << (LOGC + 1)) + 2 * tf;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const f4v q = *reinterpret_cast<const f4v *>(p + 2 * TC * e);
+      va[e] = mk(q.x, q.y);
+      vb[e] = mk(q.z, q.w);
+    }
+  }
+  __syncthreads();
+  row_passes<LOGC, 0, FWD>(va, l, s_tabh, s_x);
+  __syncthreads();
+  row_passes<LOGC, 0, FWD>(vb, l, s_tabh, s_x);
+  const int row2 = l % 16, tf2 = l / 16;
+  cpx *dst = data + tbase + blockIdx.x * 16 + row2;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int k = tf2 + TC * e;
+    const cpx p = cmulc<!FWD>(vb[e], s_tabj[k]);
+    cpx o0 = cadd(va[e], p), o1 = csub(va[e], p);
+    if constexpr (SCALE) {
+      o0 = cscale(o0, inv_n);
+      o1 = cscale(o1, inv_n);
+    }
+    st_nt(dst + ((long)k << logn1), o0);
+    st_nt(dst + ((long)(k + M) << logn1), o1);
+  }
+}
+
 template <int LOGN1>
 static hipError_t launch_big2_cols(const BigGeom &g, bool fwd, const cpx *data, cpx *scratch, const cpx *bigtabs,
                                    long batch, hipStream_t s) {
@@ -1539,13 +1624,31 @@ static hipError_t launch_fft_big2(const BigGeom &g, bool fwd, bool scale, cpx *d
   switch (g.logn1) {
     case 8: e = launch_big2_cols<8>(g, fwd, data, scratch, bigtabs, batch, s); break;
     case 9: e = launch_big2_cols<9>(g, fwd, data, scratch, bigtabs, batch, s); break;
-    case 10: e = launch_big2_cols<10>(g, fwd, data, scratch, bigtabs, batch, s); break;
+    case 10:
+      if (g.two_run) {
+        const dim3 grid((1 << g.logn2) / 16, (unsigned)batch);
+        if (fwd) hipLaunchKernelGGL((k_big2_cols_2x<true>), grid, dim3(512), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+        else hipLaunchKernelGGL((k_big2_cols_2x<false>), grid, dim3(512), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+        e = hipGetLastError();
+      } else {
+        e = launch_big2_cols<10>(g, fwd, data, scratch, bigtabs, batch, s);
+      }
+      break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
   switch (g.logn2) {
     case 9: return launch_big2_rows<9>(g, fwd, scale, scratch, data, sub.half, batch, s);
-    case 10: return launch_big2_rows<10>(g, fwd, scale, scratch, data, sub.half, batch, s);
+    case 10:
+      if (g.two_run) {
+        const dim3 grid((1 << g.logn1) / 16, (unsigned)batch);
+        const float inv_n = 1.0f / (float)(1L << g.logn);
+        if (fwd && scale) hipLaunchKernelGGL((k_big2_rows_2x<true, true>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
+        else if (fwd) hipLaunchKernelGGL((k_big2_rows_2x<true, false>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
+        else hipLaunchKernelGGL((k_big2_rows_2x<false, false>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
+        return hipGetLastError();
+      }
+      return launch_big2_rows<10>(g, fwd, scale, scratch, data, sub.half, batch, s);
     default: return hipErrorInvalidValue;
   }
 }

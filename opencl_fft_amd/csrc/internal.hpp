@@ -77,6 +77,7 @@ hipError_t launch_fft_res16(bool fwd, bool scale, cpx *data, cpx *slots, const c
 constexpr int kBigMaxLog = 24;
 struct BigGeom {
   int logn, logn1, logn2, loglo;   // n = 2^logn1 x 2^logn2; twiddle tables lo (2^loglo) / hi (n >> loglo)
+  bool two_run;                    // two-pass sizes: 1024-point columns / rows as two 512-point runs (two workgroups per CU)
 };
 int big_split(int logn, BigGeom *g);
 // bigtabs: [half N1 | lo | hi]; sub: tables of the 2^logn2 row transform; scratch holds `batch`

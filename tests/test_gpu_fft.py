@@ -366,12 +366,20 @@ def test_config3_full_size_roundtrip():
 # own to compare with: the yardstick is numpy's float64 FFT under the reference's conventions
 # (forward scaled by 1/n, inverse unscaled), same norm-relative 1e-6 criterion.
 
-@pytest.mark.parametrize("logn,batch", [(17, 3), (18, 2), (19, 1), (20, 2), (21, 1), (22, 1), (24, 1)])
-def test_cfft_big_sizes(logn, batch):
+@pytest.mark.parametrize("logn,batch,one_run", [(17, 3, False), (18, 2, False), (19, 1, False), (20, 2, False), (19, 2, True),
+                                                (20, 1, True), (21, 1, False), (22, 1, False), (24, 1, False)])
+def test_cfft_big_sizes(logn, batch, one_run):
+    """(one_run: the 1024-point column / row blocks of 2^19 and 2^20 in their one-workgroup-per-CU form, behind its
+    plan-time switch; the default is two 512-point runs per column / row, two workgroups per CU)"""
     n = 1 << logn
     rng = np.random.default_rng(logn)
     x = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
-    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    if one_run:
+        os.environ["CLFA_BIG2X"] = "0"
+    try:
+        f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
+    finally:
+        os.environ.pop("CLFA_BIG2X", None)
     assert f.get_error() == 0 and i.get_error() == 0
     assert f.workspace_bytes() >= 8 * n
     y = x.copy()
