@@ -102,6 +102,36 @@ def cpu_baseline_c2c(n, sample):
             "sample": "%d transforms of N=%d (%.1f s wall, OpenMP over batches)" % (sample, n, dt)}
 
 
+def cpu_baseline_rfft(size, sample):
+    """oracle (Clrfft::transform forward, cl_fft.cpp:267-282, restated) on all host cores over `sample` transforms"""
+    import numpy as np
+    from oracle import oracle
+    x = np.random.default_rng(0).random((sample, size), dtype=np.float32) * 2 - 1
+    oracle.rfft_forward(x[:8])
+    t0 = time.perf_counter()
+    oracle.rfft_forward(x)
+    dt = time.perf_counter() - t0
+    return {"value": sample * size / dt / 1e9, "unit": "Gsamples/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "%d r2c transforms of size %d (%.1f s wall, OpenMP over batches)" % (sample, size, dt)}
+
+
+def cpu_baseline_pconv(cvs, pts, blocks):
+    """oracle (Clpconv::convolution, cl_conv.cpp:393-458, restated: one instance, scalar) over `blocks` blocks of one channel"""
+    import numpy as np
+    from oracle import oracle
+    rng = np.random.default_rng(0)
+    o = oracle.Pconv(cvs, pts)
+    o.push_ir((rng.random(cvs, dtype=np.float32) - 0.5) / np.float32(cvs ** 0.5))
+    x = rng.random((blocks, pts), dtype=np.float32) * 2 - 1
+    o.convolution(x[0])
+    t0 = time.perf_counter()
+    for b in range(blocks):
+        o.convolution(x[b])
+    dt = time.perf_counter() - t0
+    return {"value": blocks * pts / dt / 1e9, "unit": "Gsamples/s", "cores": 1, "kind": "port",
+            "sample": "%d blocks of one channel, pts=%d, %d partitions (%.1f s wall, one thread)" % (blocks, pts, cvs // pts, dt)}
+
+
 class Workload:
     """one configuration of BASELINE.json, device-resident: step(k) launches one pass on `stream`"""
 
@@ -259,6 +289,7 @@ def main():
     import torch
     import torch.distributed as dist
     import opencl_fft_amd as fa
+    from opencl_fft_amd import _lib
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -323,7 +354,13 @@ def main():
     extra["effective_warmup_launches"] = wl.launches_before_timed
     elapsed, avg_ms, per_launch_ms = wl.timed(K, barrier, series=bool(a.series_out))
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank = None
     if world > 1:
+        # every rank's own figures, so that the N > 1 line describes itself: time, kernel-only time, device, kernel
+        mine = {"rank": rank, "device": fa.device_name(local), "kernel": wl.kernel, "elapsed_s": elapsed, "avg_launch_ms": avg_ms,
+                "gsamples_per_s": wl.units * K / elapsed / 1e9, "shard_start": extra.get("shard_start"), "batch": wl.batch}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     if cold is not None:
@@ -336,10 +373,33 @@ def main():
         extra["launch_ms"] = {"fwd_avg": sum(fwd_ms) / len(fwd_ms), "fwd_min": min(fwd_ms), "fwd_max": max(fwd_ms),
                               "inv_avg": sum(inv_ms) / len(inv_ms), "inv_min": min(inv_ms), "inv_max": max(inv_ms)}
 
+    # 3b. the same workload OUT OF PLACE (extension clfa_fft_exec_dev_oop; the reference's device side is out of place
+    # too, data1 -> data2, cl_fft.cpp:138-151): forward A -> B, inverse B -> A, same machinery.  Never the headline.
+    oop = None
+    if a.workload == "c2c" and world == 1 and not a.series_out and not os.environ.get("CLFA_BENCH_NO_OOP"):
+        other = torch.empty_like(wl.data)
+        bufs = (wl.data, other)
+        in_place_step = wl.step
+        wl.step = lambda k: wl.plans[k & 1].exec_device_oop(bufs[k & 1], bufs[1 - (k & 1)], wl.batch, stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            wl.run(max(W, 4) & ~1)
+        before = wl.launches_before_timed
+        K2 = (max(K, 20) + 1) & ~1                 # an even count: the data end where they started
+        o_s, o_ms, _ = wl.timed(K2, barrier)
+        wl.step = in_place_step
+        wl.launches_before_timed = before           # (bookkeeping of the in-place headline only)
+        oop = {"what": "the same transforms through clfa_fft_exec_dev_oop: forward A -> B, inverse B -> A (two 2 GiB buffers)",
+               "steps": K2, "ms_per_step": o_s / K2 * 1e3, "value": wl.units * K2 / o_s / 1e9, "unit": "Gsamples/s",
+               "roofline": {"bound": "hbm", "achieved": wl.alg_bytes / (o_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": wl.alg_bytes / (o_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": o_ms,
+                            "kernel": wl.kernel}}
+        del other, bufs
+        torch.cuda.empty_cache()
+
     # 4. configs[2] and configs[3] in the same run (N = 1 only: the multi-GPU line stays the sharded headline)
     others = None
     if world == 1 and not a.no_other_workloads and not a.series_out and a.batch == 0:
-        others = {}
+        others, other_names = {}, []
         for name in ("c2c", "rfft", "pconv"):
             if name == a.workload:
                 continue
@@ -359,6 +419,7 @@ def main():
             if name == "pconv":
                 rec["realtime_ratio"] = (1024 / 48000.0) / (ms2 * 1e-3)   # one block = pts / 48 kHz of audio per channel
             others[name] = rec
+            other_names.append(name)
             del o
             torch.cuda.empty_cache()
 
@@ -410,6 +471,24 @@ def main():
                             }, **extra),
             "roofline": wl.roofline(avg_ms),
         }
+        rec["config"]["library"] = os.path.relpath(_lib.LIB_PATH, ROOT)   # which build produced the number (CLFA_LIB_PATH)
+        if world > 1:
+            rec["config"]["rccl_world_size"] = dist.get_world_size()
+            rec["config"]["backend"] = dist.get_backend()
+            rec["config"]["per_gpu_gsamples"] = [r["gsamples_per_s"] for r in per_rank]
+            rec["config"]["per_rank"] = per_rank
+        if oop is not None:
+            rec["config"]["out_of_place"] = oop
+        if a.workload == "c2c":
+            # the unmodified reference (Clcfft::transform, cl_fft.cpp:153-161) run on an MI355X of this pool through OpenCL by
+            # oracle/ref_driver.cpp: one transform per call, 17 launches and two PCIe copies each (a committed measurement)
+            try:
+                t_ref = np.fromfile(os.path.join(ROOT, "tests", "golden", "ref", "timing_ref_cfft65536.bin"), dtype=np.float64)
+                rec["reference_opencl_same_gpu"] = {"value": float(t_ref[1]), "unit": "Gsamples/s", "us_per_transform": float(t_ref[0]),
+                                                    "kind": "reference", "what": "Clcfft::transform N=65536, one transform per call, "
+                                                    "PCIe copies included", "source": "tests/golden/ref/timing_ref_cfft65536.bin"}
+            except OSError:
+                pass
         if cold is not None:
             # the contract's W + K launches read cold (before the self-check): inside the chip's start-up clock ramp
             rec["ms_per_step_cold"] = cold["ms_per_step"]
@@ -433,6 +512,11 @@ def main():
                 f.write("\n".join("%.4f" % t for t in per_launch_ms) + "\n")
         if world == 1 and not a.no_cpu_baseline and a.workload == "c2c":
             rec["cpu_baseline"] = cpu_baseline_c2c(65536, 2048)
+            if others is not None:     # the other two legs against their own restatements (bounded samples, after every timed region)
+                if "rfft" in others:
+                    others["rfft"]["cpu_baseline"] = cpu_baseline_rfft(16384, 32768)
+                if "pconv" in others:
+                    others["pconv"]["cpu_baseline"] = cpu_baseline_pconv(96256, 1024, 4000)
         else:
             rec["cpu_baseline"] = None
         print(json.dumps(rec), flush=True)

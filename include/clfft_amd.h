@@ -105,6 +105,13 @@ CLFA_API int clfa_rfft_transform(clfa_fft *plan, float *c, float *r, long batch)
  * Clcfft::fft() (cl_fft.cpp:138-151) / the kernel part of Clrfft::transform.
  * data: batch * n complex64 (c2c) or batch * size float32 (r2c, packed in place). */
 CLFA_API int clfa_fft_exec_dev(clfa_fft *plan, void *data, long batch, void *stream);
+/* the same from `src` to `dst` (extension).  The reference's device side is itself out of place — its `reorder` gathers
+ * data1 -> data2 and the stages then run on data2, cl_fft.cpp:138-151 — and on MI355X a kernel that reads one buffer and
+ * writes another is ~3 % faster than the same kernel in place: complex n = 65536 in batches (the
+ * resident kernel) runs natively src -> dst; every other plan copies src to dst on the stream and transforms dst in
+ * place (correct, one more pass).  src == dst is clfa_fft_exec_dev; partly overlapping buffers are CLFA_INVALID_VALUE.
+ * `src` is left untouched. */
+CLFA_API int clfa_fft_exec_dev_oop(clfa_fft *plan, const void *src, void *dst, long batch, void *stream);
 /* bytes of device workspace a plan holds (0 for single-pass sizes) */
 CLFA_API size_t clfa_fft_workspace_bytes(const clfa_fft *plan);
 /* name of the HIP kernel that does the work for this plan (for profiles) */

@@ -124,6 +124,13 @@ class _Plan:
         p, stream = _ptr_stream(data, stream)
         return lib().clfa_fft_exec_dev(self._h, p, batch, stream)
 
+    def exec_device_oop(self, src, dst, batch, stream=None):
+        """src -> dst on device memory (extension; the reference's device side is out of place too: data1 -> data2,
+        cl_fft.cpp:138-151); src is left untouched"""
+        ps, stream = _ptr_stream(src, stream)
+        pd, _ = _ptr_stream(dst, stream)
+        return lib().clfa_fft_exec_dev_oop(self._h, ps, pd, batch, stream)
+
 
 class Clcfft(_Plan):
     """cl_fft::Clcfft(device_id, size, fwd=true) (cl_fft.h:29-70, cl_fft.cpp:44-161)"""

@@ -10,6 +10,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (CLFA_LIB_PATH: another build of the same library, for A/B runs of bench.py — tools/build_variant.sh)
 LIB_PATH = os.environ.get("CLFA_LIB_PATH") or os.path.join(_HERE, "libclfft_amd.so")
+if os.environ.get("CLFA_LIB_PATH"):   # a development hook: never silently (bench.py also records the path in its line)
+    import sys
+    print("opencl_fft_amd: CLFA_LIB_PATH is set, loading %s instead of the in-tree library" % LIB_PATH, file=sys.stderr)
 
 # every symbol include/clfft_amd.h declares: (name, restype, argtypes)
 _vp, _fp, _ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
@@ -29,6 +32,7 @@ SYMBOLS = [
     ("clfa_cfft_transform", C.c_int, [_vp, _vp, C.c_long]),
     ("clfa_rfft_transform", C.c_int, [_vp, _vp, _vp, C.c_long]),
     ("clfa_fft_exec_dev", C.c_int, [_vp, _vp, C.c_long, _vp]),
+    ("clfa_fft_exec_dev_oop", C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
     ("clfa_fft_workspace_bytes", C.c_size_t, [_vp]),
     ("clfa_fft_kernel_name", C.c_char_p, [_vp]),
     ("clfa_reorder_dev", C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_long, _vp]),

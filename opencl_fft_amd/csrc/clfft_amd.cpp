@@ -767,6 +767,26 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   return CLFA_SUCCESS;
 }
 
+int clfa_fft_exec_dev_oop(clfa_fft *p, const void *src, void *dst, long batch, void *stream) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!src || !dst || batch < 0) return CLFA_INVALID_VALUE;
+  if (src == dst) return clfa_fft_exec_dev(p, dst, batch, stream);
+  if (batch == 0) return CLFA_SUCCESS;
+  const size_t bytes = sizeof(cpx) * (size_t)p->n * (size_t)batch;   // real plans: n = size / 2 packed bins = size floats
+  const char *a = (const char *)src, *b = (const char *)dst;
+  if (a < b + bytes && b < a + bytes) return CLFA_INVALID_VALUE;     // partly overlapping
+  ENTER_DEVICE(p->di.device);
+  hipStream_t s = (hipStream_t)stream;
+  if (!p->real && !p->blue_m && p->logn == 16 && batch * 4 > p->di.num_cus) {
+    HIP_TRY(p->order.use(s));
+    HIP_TRY(launch_fft_res16(p->fwd, p->fwd, (const cpx *)src, (cpx *)dst, (cpx *)p->scratch.p, p->tabs.res16, batch, p->di, s));
+    return CLFA_SUCCESS;
+  }
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  return clfa_fft_exec_dev(p, dst, batch, stream);
+}
+
 // bytes per call up to which the host entry points go zero-copy: the kernels read the input from,
 // and write the result to, mapped pinned host memory (one pass each way), instead of two
 // hipMemcpyAsync calls of 10-15 us each around a kernel of a few microseconds

@@ -28,6 +28,22 @@
 
 namespace clfa {
 
+// ---- which transform a workgroup of a persistent kernel starts with (it then steps by the grid size) ----------------
+// Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md: blocks i and i + 8 share one).  With
+// "workgroup i takes transform i" every XCD works on every eighth transform of the window of gridDim.x transforms the
+// chip is in; here XCD x takes the x-th CONTIGUOUS eighth of that window (workgroup i = x + 8 c starts at
+// x * (G / 8) + c), so that the workgroups behind one L2 stream through one compact address range.  Same windows,
+// same step, any batch; measured on the resident n = 65536 kernel: 0.871 -> 0.831 ms per 4096 transforms
+// (profiles/r04_assignment.txt; tools/res16_probe.hip PROBE_PERM sweeps the other assignments).
+#ifndef CLFA_XCD_MAP
+#define CLFA_XCD_MAP 1
+#endif
+CLFA_HD long xcd_first(unsigned i, unsigned grid) {
+  if (!CLFA_XCD_MAP || (grid & 7)) return i;
+  return (long)(i & 7) * (grid >> 3) + (i >> 3);
+}
+
+
 // A complex value is a native 2-float vector on the device (and wherever clang compiles this
 // header): it lives in an aligned VGPR pair from the 8-byte load to the 8-byte store, and the
 // arithmetic below is CDNA's packed fp32 (v_pk_add/mul/fma_f32: both halves per instruction, the

@@ -21,6 +21,12 @@
 #include <type_traits>
 
 namespace clfa {
+#ifdef CLFA_ASSIGN_SEARCH
+// dev builds only (tools/assign_search.py): the transform -> workgroup assignment of k_fft_lds as a bit permutation:
+// [0] bits of (workgroup | iteration << [1]) in use (0: off), [1] log2(grid), [2 + j] source bit of bit j of the transform index
+__device__ int g_assign[40];
+#endif
+
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -190,6 +196,25 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   const int f = FPW == 1 ? 0 : tid / T, t = FPW == 1 ? tid : tid % T;   // (FPW == 1: the base stays provably uniform)
   const long groups = (batch + FPW - 1) / FPW;
   long g = blockIdx.x;
+#ifdef CLFA_ASSIGN_SEARCH
+  long kk = 0;
+  int a_sh[16];   // read once (scalar loads), then SGPRs
+  const bool a_on = g_assign[0] && (1u << g_assign[1]) == gridDim.x;
+  const int a_lg = g_assign[1];
+#pragma unroll
+  for (int j = 0; j < 16; j++) a_sh[j] = j < g_assign[0] ? g_assign[2 + j] : 63;
+  auto amap = [&](long k) -> long {
+    if (!a_on) return blockIdx.x + k * gridDim.x;
+    const long vv = blockIdx.x | (k << a_lg);
+    long r = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) r |= ((vv >> a_sh[j]) & 1) << j;
+    r = r < groups ? r : groups - 1;   // a table that does not fit the launch must not leave the buffer
+    return __builtin_amdgcn_readfirstlane((int)r);
+  };
+  g = amap(0);
+  const long per_ = (groups + gridDim.x - 1) / gridDim.x;
+#endif
   if (g >= groups) return;   // whole workgroup (uniform): launchers never over-provision the grid
   // the first transform's loads are issued before anything else: they fly while the tables are filled
   cpx v[E], vn[E];
@@ -261,7 +286,11 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   for (int e = 0; e < E; e++) asm volatile("" : "+v"(v[e]));
   const int t_invariant = t;
 #pragma unroll 1
+#ifdef CLFA_ASSIGN_SEARCH
+  for (; kk < per_; g = amap(++kk)) {
+#else
   for (; g < groups; g += gridDim.x) {
+#endif
     // Re-derive the lane index inside the loop through an opaque move: otherwise hipcc hoists every
     // LDS scatter/gather offset and global offset of all passes out of the batch loop, keeps
     // ~100 of them live across it and spills them (seen in the ISA as scratch stores in the
@@ -281,6 +310,9 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     if constexpr (G::PREFETCH) {
       long gn = g + gridDim.x;
       gn = gn < groups ? gn : groups - 1;
+#ifdef CLFA_ASSIGN_SEARCH
+      gn = kk + 1 < per_ ? amap(kk + 1) : g;
+#endif
       const long bn = gn * FPW + f;
       lds_fft_load<LOGN, MODE, FWD>(vn, data + (bn < batch ? bn : batch - 1) * (long)N, t);
     }
@@ -409,6 +441,9 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       // no prefetch: load the next transform now (clamped, straight-line)
       long gn = g + gridDim.x;
       gn = gn < groups ? gn : groups - 1;
+#ifdef CLFA_ASSIGN_SEARCH
+      gn = kk + 1 < per_ ? amap(kk + 1) : g;
+#endif
       const long bn = gn * FPW + f;
       lds_fft_load<LOGN, MODE, FWD>(v, data + (bn < batch ? bn : batch - 1) * (long)N, t);
     }
@@ -1131,9 +1166,9 @@ __global__ __launch_bounds__(512) void k_fft_4step(cpx *__restrict__ data, cpx *
   // prefetching form: the first column block of a transform is loaded behind the last row block of the
   // previous one (`vnext`), so that only the very first load of the workgroup is exposed
   cpx vnext[16];
-  if constexpr (PF) four_load1<LOGN, NT ? 1 : 0>(vnext, data + (long)blockIdx.x * G::N, slice, l);
+  if constexpr (PF) four_load1<LOGN, NT ? 1 : 0>(vnext, data + xcd_first(blockIdx.x, gridDim.x) * G::N, slice, l);
 #pragma unroll 1
-  for (long b = blockIdx.x; b < batch; b += gridDim.x) {
+  for (long b = xcd_first(blockIdx.x, gridDim.x); b < batch; b += gridDim.x) {
     cpx *x = data + b * (long)G::N;
     {
       // software-prefetched form: the next block's loads fly behind the current block's passes.
@@ -1292,7 +1327,7 @@ static hipError_t launch_4step_v(cpx *data, cpx *scratch, const FftTables &t, lo
   }
   if constexpr (LOGN == 16) {
     // n = 65536: the resident kernel (fft_resident.hip); `scratch` provides its per-workgroup slots
-    return launch_fft_res16(FWD, SCALE, data, scratch, t.res16, batch, di, s);
+    return launch_fft_res16(FWD, SCALE, data, data, scratch, t.res16, batch, di, s);
   } else {
     if (batch < grid) grid = (int)batch;
     hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE>), dim3(grid), dim3(512), 0, s, data, scratch, t.four, batch);
@@ -1795,3 +1830,9 @@ hipError_t launch_reorder(cpx *out, const cpx *in, int logn, long batch, hipStre
 }
 
 }  // namespace clfa
+
+#ifdef CLFA_ASSIGN_SEARCH
+extern "C" __attribute__((visibility("default"))) int clfa_debug_set_assign(const int *h, int n) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(clfa::g_assign), h, (size_t)n * 4);
+}
+#endif

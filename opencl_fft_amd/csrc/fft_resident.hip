@@ -55,22 +55,15 @@
 namespace clfa {
 namespace {
 
-// cache policy of the streams (tuning switches for A/B builds; the library's choice is the default)
-#ifndef CLFA_NT_LD
-#define CLFA_NT_LD 1
-#endif
-#ifndef CLFA_NT_ST
-#define CLFA_NT_ST 1
-#endif
-#if CLFA_NT_LD
+// cache policy of the streams (tuning switches for A/B builds; the library's choice is the default):
+// CLFA_LDNT / CLFA_STNT = the modifier string of the asm accesses, CLFA_ST_AUX = the same policy as the aux
+// operand of the store builtin (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#ifndef CLFA_LDNT
 #define CLFA_LDNT " nt"
-#else
-#define CLFA_LDNT ""
 #endif
-#if CLFA_NT_ST
+#ifndef CLFA_STNT
 #define CLFA_STNT " nt"
-#else
-#define CLFA_STNT ""
+#define CLFA_ST_AUX 2
 #endif
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -155,7 +148,7 @@ template <int PROBE = 0> __device__ __forceinline__ void res_store(const cpx (&v
       cpx t = v[e];
       asm volatile("" : "+v"(t));
     } else {
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v[e]), r, voff, e * 32768, CLFA_NT_ST ? 2 : 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v[e]), r, voff, e * 32768, CLFA_ST_AUX);
     }
   }
 }
@@ -578,7 +571,7 @@ __device__ __forceinline__ void res_probe_grid_sync(unsigned long long *dbg, uns
 
 // slots: one 32 KiB slot per workgroup (the single row block that does not fit the CU)
 template <bool FWD, bool SCALE, int PROBE = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_fft_res16(cpx *__restrict__ data, cpx *__restrict__ slots,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_fft_res16(const cpx *data, cpx *out, cpx *__restrict__ slots,
                                                    const cpx *__restrict__ tabs_g, long batch,
                                                    unsigned long long *__restrict__ dbg = nullptr) {
 #ifndef CLFA_RES16_PROBE
@@ -627,7 +620,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
 #pragma unroll
   for (int j = 0; j < kVgprBlk; j++) K[j] = 0.f;
   cpx v[16];
-  long b = blockIdx.x;
+  long b = xcd_first(blockIdx.x, gridDim.x);   // XCD-compact assignment (fft_device.hpp)
+#ifdef CLFA_RES16_PROBE
+  // probe only: other transform -> workgroup assignments (dbg[3000]; needs batch % (16 * gridDim.x) == 0): 0 the library's,
+  // 5 workgroup i takes i, i + G, ... (rounds 1-3), 1 chunks (i * per + k), 2 / 3 mixtures, 4 a bit permutation
+  const int mapmode = dbg ? (int)dbg[3000] : 0;
+  const long per = batch / gridDim.x;
+  long kk = 0;
+  auto bmap = [&](long k) -> long {
+    const long i = blockIdx.x;
+    switch (mapmode) {
+      case 1: return i * per + k;
+      case 2: return (i & 15) + 16 * k + 16 * per * (i >> 4);
+      case 3: return (i >> 4) + (gridDim.x >> 4) * k + (gridDim.x >> 4) * per * (i & 15);
+      case 4: {   // bit j of b = bit dbg[3001 + j] of (i | k << 8), 12 bits (256 workgroups x 16 transforms)
+        const long v = i | (k << 8);
+        long r = 0;
+        for (int j = 0; j < 12; j++) r |= ((v >> dbg[3001 + j]) & 1) << j;
+        return __builtin_amdgcn_readfirstlane((int)r);
+      }
+      case 5: return i + k * gridDim.x;
+      default: return xcd_first(blockIdx.x, gridDim.x) + k * gridDim.x;   // the library's
+    }
+  };
+  b = bmap(0);
+#endif
 #ifdef CLFA_RES16_PROBE
   unsigned long long clk1 = 0, clk2 = 0;
   unsigned epoch = 0;   // probe only (the host zeroes the counter before the launch)
@@ -645,8 +662,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     res_load_land(data + b * (long)kN + ((1 + rot) & 15) * 16, L0.voff);
   }
 #pragma unroll 1
+#ifdef CLFA_RES16_PROBE
+  for (; kk < per; kk++, b = bmap(kk)) {
+#else
   for (; b < batch; b += gridDim.x) {
-    cpx *x = data + b * (long)kN;
+#endif
+    const cpx *x = data + b * (long)kN;
+    cpx *y = out + b * (long)kN;   // out == data: in place
 #ifdef CLFA_RES16_PROBE
     unsigned long long t0 = 0;
     if constexpr (PROBE & kProbeStamps) t0 = __builtin_amdgcn_s_memtime();
@@ -685,6 +707,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     // are parked in the landing registers and stored while the next block is computed.
     long bn = b + gridDim.x;   // next transform (clamped: its first loads are issued unconditionally)
     bn = bn < batch ? bn : batch - 1;
+#ifdef CLFA_RES16_PROBE
+    bn = bmap(kk + 1 < per ? kk + 1 : kk);
+#endif
     const cpx *xn = data + bn * (long)kN;
     {
       const ResLane L = lane();
@@ -709,7 +734,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
         if (it == 13) res_load_acc<kZone0>(xn + (rot & 15) * 16, L.voff);
       }
       if constexpr (!(PROBE & kProbeNoStore)) {
-        res_row_block<FWD, PROBE>(v, L, HookStore{res_rsrc(x + ((rb_prev + rot) & 15) * 16), L.voff, so});
+        res_row_block<FWD, PROBE>(v, L, HookStore{res_rsrc(y + ((rb_prev + rot) & 15) * 16), L.voff, so});
       } else {
         res_row_block<FWD, PROBE>(v, L);
       }
@@ -720,11 +745,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       const ResLane L = lane();
       res_fetch_static<2>(v, L, K);
       if constexpr (!(PROBE & kProbeNoStore)) {
-        res_row_block<FWD, PROBE>(v, L, HookStore{res_rsrc(x + ((rb_prev + rot) & 15) * 16), L.voff, so});
+        res_row_block<FWD, PROBE>(v, L, HookStore{res_rsrc(y + ((rb_prev + rot) & 15) * 16), L.voff, so});
       } else {
         res_row_block<FWD, PROBE>(v, L);
       }
-      res_store<PROBE>(v, res_rsrc(x + ((2 + rot) & 15) * 16), L.voff);
+      res_store<PROBE>(v, res_rsrc(y + ((2 + rot) & 15) * 16), L.voff);
       // the next transform's block 1 -> landing registers (after this block's parked stores have been issued)
       if constexpr (!(PROBE & kProbeNoLoad)) res_load_land(xn + ((1 + rot) & 15) * 16, L.voff);
     }
@@ -747,13 +772,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
 #endif
 }
 
-hipError_t launch_fft_res16(bool fwd, bool scale, cpx *data, cpx *slots, const cpx *tabs, long batch,
+hipError_t launch_fft_res16(bool fwd, bool scale, const cpx *data, cpx *out, cpx *slots, const cpx *tabs, long batch,
                             const DeviceInfo &di, hipStream_t s) {
   if (batch <= 0) return hipSuccess;
   const int grid = (int)(batch < di.num_cus ? batch : di.num_cus);
-  if (fwd && scale) hipLaunchKernelGGL((k_fft_res16<true, true>), dim3(grid), dim3(256), 0, s, data, slots, tabs, batch);
-  else if (fwd) hipLaunchKernelGGL((k_fft_res16<true, false>), dim3(grid), dim3(256), 0, s, data, slots, tabs, batch);
-  else if (!scale) hipLaunchKernelGGL((k_fft_res16<false, false>), dim3(grid), dim3(256), 0, s, data, slots, tabs, batch);
+  if (fwd && scale) hipLaunchKernelGGL((k_fft_res16<true, true>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch);
+  else if (fwd) hipLaunchKernelGGL((k_fft_res16<true, false>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch);
+  else if (!scale) hipLaunchKernelGGL((k_fft_res16<false, false>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -71,7 +71,8 @@ int fourstep_split(int logn, int *logn1, int *logn2, int *loglo);
 constexpr int kRes16TabSize = 1792;
 // slots: 32 KiB per workgroup, grid = min(batch, CUs) workgroups (kRes16SlotBytes each)
 constexpr size_t kRes16SlotBytes = 32768;
-hipError_t launch_fft_res16(bool fwd, bool scale, cpx *data, cpx *slots, const cpx *tabs, long batch,
+// out == data: in place (what every plan does); out != data: out of place (measured in tools/res16_probe.hip)
+hipError_t launch_fft_res16(bool fwd, bool scale, const cpx *data, cpx *out, cpx *slots, const cpx *tabs, long batch,
                             const DeviceInfo &di, hipStream_t s);
 // n = 2^17 .. 2^kBigMaxLog (extension: the reference overflows above 65536): columns + rows + transpose
 constexpr int kBigMaxLog = 24;

@@ -180,6 +180,57 @@ def test_cfft_batched_kernels_vs_reference_vectors(n):
         assert np.array_equal(y.view(np.uint32), np.tile(y[0], (batch, 1)).view(np.uint32)), "transforms of one batch differ"
 
 
+@pytest.mark.parametrize("n,batch", [(65536, 70), (65536, 300), (1024, 9), (16384, 70), (65536, 3)])
+def test_cfft_out_of_place(n, batch):
+    """clfa_fft_exec_dev_oop (extension; the reference's device side is out of place too, cl_fft.cpp:138-151): the resident
+    kernel src -> dst for n = 65536 in batches, copy + in place for every other plan; the source stays untouched, and the
+    result is the reference's vector (golden input replicated) in every transform, forward and inverse"""
+    import torch
+    x = np.tile(util.lcg_complex(12345, n), (batch, 1))
+    for fwd in (True, False):
+        plan = fa.Clcfft(0, n, fwd)
+        src = torch.from_numpy(x.view(np.float32).reshape(batch, n, 2).copy()).cuda()
+        dst = torch.full_like(src, float("nan"))
+        assert plan.exec_device_oop(src, dst, batch) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(src.cpu().numpy().view(np.uint32), x.view(np.uint32).reshape(batch, n, 2)), "source modified"
+        y = dst.cpu().numpy().view(np.complex64).reshape(batch, n)
+        name = "g4_cfft%d_%s_dec" % (n, "fwd" if fwd else "inv") if n >= 16384 else "g3_cfft1024_%s" % ("fwd" if fwd else "inv")
+        ref = golden(name)
+        for b in range(batch):
+            assert_parity(util.decimate(y[b]) if n >= 16384 else y[b], ref, what="oop n=%d fwd=%s transform %d vs reference" % (n, fwd, b))
+        # the same bits as the in-place entry point
+        assert plan.exec_device(src, batch) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(src.view(torch.int32), dst.view(torch.int32)), "out of place and in place differ"
+
+
+def test_cfft_out_of_place_arguments():
+    import torch
+    n, batch = 65536, 70
+    plan = fa.Clcfft(0, n, True)
+    buf = torch.zeros((2 * batch, n, 2), device="cuda")
+    assert plan.exec_device_oop(buf, buf, batch) == 0                       # src == dst: in place
+    assert plan.exec_device_oop(buf, buf[1:], batch) == fa.CL_INVALID_VALUE     # partly overlapping
+    assert plan.exec_device_oop(buf[1:], buf, batch) == fa.CL_INVALID_VALUE
+    assert plan.exec_device_oop(buf, buf[batch:], batch) == 0               # adjacent, disjoint
+    assert plan.exec_device_oop(buf, buf[batch:], 0) == 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("size,batch", [(16384, 11), (65536, 40)])
+def test_rfft_out_of_place(size, batch):
+    """real plans through the out-of-place entry point (copy + in place): oracle parity, source untouched"""
+    import torch
+    r = (np.random.default_rng(size).random((batch, size), dtype=np.float32) * 2 - 1)
+    src = torch.from_numpy(r.copy()).cuda()
+    dst = torch.empty_like(src)
+    assert fa.Clrfft(0, size, True).exec_device_oop(src, dst, batch) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(src.cpu().numpy(), r)
+    assert_parity(dst.cpu().numpy().view(np.complex64), oracle.rfft_forward(r), what="rfft oop size %d" % size)
+
+
 @pytest.mark.parametrize("size,kernel", [(8192, "k_rfft_2x"), (8192, "k_fft_lds"), (32768, "k_rfft_2x"), (32768, "k_fft_lds"),
                                          (65536, "k_rfft_2x"), (131072, None)])
 def test_rfft_batched_kernels_vs_reference_vectors(size, kernel):

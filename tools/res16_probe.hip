@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 using namespace clfa;
 
@@ -22,6 +23,8 @@ using namespace clfa;
     }                                                                 \
   } while (0)
 
+static cpx *g_out = nullptr;   // != nullptr: the launches write there (out of place)
+
 template <int PROBE> static void run(const char *name, cpx *data, cpx *slots, cpx *tabs, unsigned long long *dbg, long batch, int cus) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -29,7 +32,7 @@ template <int PROBE> static void run(const char *name, cpx *data, cpx *slots, cp
   const int warm = 10, reps = 40;
   auto launch = [&] {
     if (PROBE & 512) CK(hipMemsetAsync(dbg + 1024, 0, 8, 0));
-    hipLaunchKernelGGL((k_fft_res16<true, false, PROBE>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, dbg);
+    hipLaunchKernelGGL((k_fft_res16<true, false, PROBE>), dim3(cus), dim3(256), 0, 0, data, g_out ? g_out : data, slots, tabs, batch, dbg);
   };
   for (int i = 0; i < warm; i++) launch();
   CK(hipEventRecord(e0));
@@ -76,7 +79,7 @@ static void run_slots(cpx *data, cpx *slots, cpx *tabs, unsigned long long *dbg,
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  auto launch = [&] { hipLaunchKernelGGL((k_fft_res16<true, false, 1024 | 16>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, dbg); };
+  auto launch = [&] { hipLaunchKernelGGL((k_fft_res16<true, false, 1024 | 16>), dim3(cus), dim3(256), 0, 0, data, g_out ? g_out : data, slots, tabs, batch, dbg); };
   for (int i = 0; i < 10; i++) launch();
   CK(hipEventRecord(e0));
   for (int i = 0; i < 40; i++) launch();
@@ -107,7 +110,7 @@ static void run_split(cpx *data, cpx *slots, cpx *tabs, long batch, int cus, int
   const long per = batch / parts;
   auto once = [&] {
     for (int p = 0; p < parts; p++)
-      hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data + p * per * 65536, slots, tabs, per, (unsigned long long *)nullptr);
+      hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data + p * per * 65536, data + p * per * 65536, slots, tabs, per, (unsigned long long *)nullptr);
   };
   for (int i = 0; i < warm; i++) once();
   CK(hipEventRecord(e0));
@@ -136,11 +139,11 @@ static void run_ramp(const char *name, cpx *data, cpx *slots, cpx *tabs, long ba
   if (pre_kind == 1) {        // ALU-only activity, ~50 ms
     for (int i = 0; i < 50; i++) hipLaunchKernelGGL(k_spin, dim3(cus * 8), dim3(256), 0, 0, sink, 300000);
   } else if (pre_kind == 2) { // memory activity: 50 launches of the FFT kernel itself
-    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, (unsigned long long *)nullptr);
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data, g_out ? g_out : data, slots, tabs, batch, (unsigned long long *)nullptr);
   }
   CK(hipEventRecord(ev[0]));
   for (int i = 0; i < n; i++) {
-    hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data, g_out ? g_out : data, slots, tabs, batch, (unsigned long long *)nullptr);
     CK(hipEventRecord(ev[i + 1]));
   }
   CK(hipEventSynchronize(ev[n]));
@@ -170,6 +173,197 @@ int main() {
   for (int i = 0; i < 1792; i++) t[i] = mk((float)cos(i * 0.001), (float)sin(i * 0.001));   // unit-modulus stand-ins: timing only
   CK(hipMemcpy(tabs, t.data(), 1792 * 8, hipMemcpyHostToDevice));
   printf("k_fft_res16 probe: %ld transforms, %d workgroups\n", batch, cus);
+  if (getenv("PROBE_MAP")) {   // transform -> workgroup assignments, in place
+    for (int round = 0; round < 3; round++)
+      for (unsigned long long mode = 0; mode < 4; mode++) {
+        CK(hipMemcpy(dbg + 3000, &mode, 8, hipMemcpyHostToDevice));
+        char nm[64];
+        snprintf(nm, sizeof nm, "assignment %llu, in place", mode);
+        run<16>(nm, data, slots, tabs, dbg, batch, cus);
+      }
+    return 0;
+  }
+  if (getenv("PROBE_PERM")) {   // bit permutations of (workgroup, iteration) -> transform, in place; needs 256 CUs
+    struct P { int p[12]; float best; };
+    std::vector<P> perms;
+    auto add = [&](std::initializer_list<int> l) { P q; int j = 0; for (int x : l) q.p[j++] = x; q.best = 1e9f; perms.push_back(q); };
+    add({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11});     // the library's
+    for (int pos = 0; pos <= 8; pos++) {             // the 4 iteration bits as a group at bit `pos` of b
+      P q; int src = 0;
+      for (int j = 0; j < 12; j++) q.p[j] = (j >= pos && j < pos + 4) ? 8 + (j - pos) : src++;
+      q.best = 1e9f; perms.push_back(q);
+    }
+    for (int pos = 0; pos <= 8; pos++) {             // ... with the workgroup bits reversed (XCD bits on top)
+      P q; int src = 7;
+      for (int j = 0; j < 12; j++) q.p[j] = (j >= pos && j < pos + 4) ? 8 + (j - pos) : src--;
+      q.best = 1e9f; perms.push_back(q);
+    }
+    if (getenv("PROBE_PERM_XCD")) {                  // XCD-compact candidates only (w0..w2 = XCD, w3..w7 = workgroup in the XCD)
+      perms.resize(1);
+      add({3, 4, 5, 6, 7, 0, 1, 2, 8, 9, 10, 11});   // A: window of G transforms, XCD x takes its x-th eighth
+      add({7, 6, 5, 4, 3, 2, 1, 0, 8, 9, 10, 11});   // B: the same, bits reversed
+      add({3, 4, 5, 6, 7, 8, 9, 10, 11, 0, 1, 2});   // C: every XCD streams through its own eighth of the batch
+      add({3, 4, 5, 6, 7, 0, 8, 9, 10, 11, 1, 2});   // D
+      add({3, 4, 5, 6, 7, 0, 1, 8, 9, 10, 11, 2});   // E
+      add({8, 9, 10, 11, 3, 4, 5, 6, 7, 0, 1, 2});   // F: every workgroup takes 16 adjacent transforms, XCDs an eighth each
+      add({8, 9, 3, 4, 5, 6, 7, 10, 11, 0, 1, 2});   // G
+      add({3, 4, 5, 6, 7, 1, 2, 8, 9, 10, 11, 0});   // H: as E with the XCD's low bit on top
+      add({4, 6, 5, 7, 3, 2, 1, 8, 9, 10, 11, 0});   // the local search's best
+      add({7, 3, 6, 8, 11, 2, 5, 1, 9, 10, 0, 4});
+    }
+    unsigned sd = 12345;
+    for (int r = 0; r < (getenv("PROBE_PERM_XCD") ? 0 : 60); r++) {                   // random ones
+      P q; for (int j = 0; j < 12; j++) q.p[j] = j;
+      for (int j = 11; j > 0; j--) { sd = sd * 1664525u + 1013904223u; int o = (sd >> 8) % (j + 1); std::swap(q.p[j], q.p[o]); }
+      q.best = 1e9f; perms.push_back(q);
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int round = 0; round < (getenv("PROBE_PERM_XCD") ? 6 : 3); round++)
+      for (auto &q : perms) {
+        unsigned long long h[13] = {4};
+        for (int j = 0; j < 12; j++) h[1 + j] = q.p[j];
+        CK(hipMemcpy(dbg + 3000, h, sizeof h, hipMemcpyHostToDevice));
+        auto launch = [&] { hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data, data, slots, tabs, batch, dbg); };
+        for (int i = 0; i < 5; i++) launch();
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 20; i++) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        q.best = std::min(q.best, ms / 20);
+      }
+    CK(hipGetLastError());
+    for (auto &q : perms) {
+      printf("b bits 0..11 <- ");
+      for (int j = 0; j < 12; j++) printf(q.p[j] < 8 ? "w%d " : "k%d ", q.p[j] < 8 ? q.p[j] : q.p[j] - 8);
+      printf("  %8.3f ms\n", q.best);
+    }
+    return 0;
+  }
+  if (getenv("PROBE_SEARCH")) {   // local search over the bit permutations (pairwise swaps from the best so far), in place
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto eval = [&](const int *p, int reps) {
+      unsigned long long h[13] = {4};
+      for (int j = 0; j < 12; j++) h[1 + j] = p[j];
+      CK(hipMemcpy(dbg + 3000, h, sizeof h, hipMemcpyHostToDevice));
+      auto launch = [&] { hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, data, data, slots, tabs, batch, dbg); };
+      for (int i = 0; i < 4; i++) launch();
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < reps; i++) launch();
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      return ms / reps;
+    };
+    auto show = [&](const int *p, float ms, const char *tag) {
+      printf("%s b bits 0..11 <- ", tag);
+      for (int j = 0; j < 12; j++) printf(p[j] < 8 ? "w%d " : "k%d ", p[j] < 8 ? p[j] : p[j] - 8);
+      printf("  %8.3f ms\n", ms);
+      fflush(stdout);
+    };
+    const int starts[3][12] = {{7, 6, 5, 4, 3, 2, 1, 8, 9, 10, 11, 0}, {7, 3, 6, 8, 11, 2, 0, 1, 9, 10, 5, 4}, {10, 3, 5, 0, 8, 9, 2, 7, 11, 1, 4, 6}};
+    for (int st = 0; st < 3; st++) {
+      int cur[12];
+      for (int j = 0; j < 12; j++) cur[j] = starts[st][j];
+      float best = eval(cur, 30);
+      show(cur, best, "start ");
+      for (int sweep = 0; sweep < 3; sweep++) {
+        bool improved = false;
+        for (int a = 0; a < 12; a++)
+          for (int c = a + 1; c < 12; c++) {
+            int t[12];
+            for (int j = 0; j < 12; j++) t[j] = cur[j];
+            std::swap(t[a], t[c]);
+            float ms = eval(t, 12);
+            if (ms < best - 0.004f) {
+              ms = eval(t, 30);   // confirm
+              const float again = eval(cur, 30);
+              if (ms < again - 0.003f) {
+                for (int j = 0; j < 12; j++) cur[j] = t[j];
+                best = ms;
+                improved = true;
+                show(cur, best, "better");
+              }
+            }
+          }
+        if (!improved) break;
+      }
+      show(cur, eval(cur, 40), "final ");
+    }
+    const int lib[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+    show(lib, eval(lib, 40), "lib   ");
+    return 0;
+  }
+  if (getenv("PROBE_DELTA")) {   // dst = src + delta inside ONE allocation: which address relation of the two streams matters?
+    char *big;
+    const size_t two_g = (size_t)batch * 65536 * 8;
+    CK(hipMalloc(&big, 2 * two_g + (256u << 20)));
+    CK(hipMemset(big, 0, 2 * two_g + (256u << 20)));
+    const long deltas[] = {0, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1 << 20, 2 << 20, 4 << 20, 8 << 20,
+                           16 << 20, 32 << 20, 64 << 20, 128 << 20, (128 << 20) + 524288, (128 << 20) + 4096};
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int round = 0; round < 3; round++)
+      for (int far = 0; far < 2; far++)
+        for (long d : deltas) {
+          const cpx *src = (const cpx *)big;
+          cpx *dst = (cpx *)(big + (far ? two_g : 0) + d);
+          auto launch = [&] { hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, src, dst, slots, tabs, batch, (unsigned long long *)nullptr); };
+          for (int i = 0; i < 6; i++) launch();
+          CK(hipEventRecord(e0));
+          for (int i = 0; i < 20; i++) launch();
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          printf("dst = src + %s%10ld   %8.3f ms\n", far ? "2 GiB + " : "        ", d, ms / 20);
+        }
+    return 0;
+  }
+  if (getenv("PROBE_OOP")) {   // in place against out of place, interleaved
+    cpx *out2;
+    CK(hipMalloc(&out2, batch * 65536 * 8));
+    CK(hipMemset(out2, 0, batch * 65536 * 8));
+    for (int round = 0; round < (getenv("PROBE_PP") ? 0 : 4); round++) {
+      g_out = nullptr;
+      run<0>("full, in place", data, slots, tabs, dbg, batch, cus);
+      run<16>("full + stamps, in place", data, slots, tabs, dbg, batch, cus);
+      g_out = out2;
+      run<0>("full, OUT OF PLACE", data, slots, tabs, dbg, batch, cus);
+      run<16>("full + stamps, OUT OF PLACE", data, slots, tabs, dbg, batch, cus);
+    }
+    g_out = nullptr;
+    // ping-pong: A -> B, B -> A (every buffer is read and written in turn, as a caller alternating directions would)
+    for (int round = 0; round < 4; round++) {
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      for (int mode = 0; mode < 2; mode++) {
+        auto launch = [&](int i) {
+          const cpx *src = mode == 0 ? data : ((i & 1) ? out2 : data);
+          cpx *dst = mode == 0 ? data : ((i & 1) ? data : out2);
+          hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(cus), dim3(256), 0, 0, src, dst, slots, tabs, batch, (unsigned long long *)nullptr);
+        };
+        for (int i = 0; i < 10; i++) launch(i);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 40; i++) launch(i);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-34s %8.3f ms  %6.2f TB/s alg\n", mode ? "ping-pong A -> B, B -> A" : "in place", ms / 40, batch * 65536.0 * 16 / (ms / 40) * 1e-9);
+      }
+    }
+    return 0;
+  }
+#ifndef PROBE_OOP_ONLY   // -DPROBE_OOP_ONLY: compile the two instantiations above only
   run<0>("full", data, slots, tabs, dbg, batch, cus);
   run<16>("full + stamps", data, slots, tabs, dbg, batch, cus);
   for (unsigned p1 : {2300u, 2400u, 2500u, 2600u, 2700u})
@@ -220,8 +414,8 @@ int main() {
     for (auto &evt : ev) CK(hipEventCreate(&evt));
     CK(hipEventRecord(ev[0]));
     for (int i = 0; i < n; i++) {
-      if (i & 1) hipLaunchKernelGGL((k_fft_res16<false, false, 0>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, (unsigned long long *)nullptr);
-      else hipLaunchKernelGGL((k_fft_res16<true, true, 0>), dim3(cus), dim3(256), 0, 0, data, slots, tabs, batch, (unsigned long long *)nullptr);
+      if (i & 1) hipLaunchKernelGGL((k_fft_res16<false, false, 0>), dim3(cus), dim3(256), 0, 0, data, g_out ? g_out : data, slots, tabs, batch, (unsigned long long *)nullptr);
+      else hipLaunchKernelGGL((k_fft_res16<true, true, 0>), dim3(cus), dim3(256), 0, 0, data, g_out ? g_out : data, slots, tabs, batch, (unsigned long long *)nullptr);
       CK(hipEventRecord(ev[i + 1]));
     }
     CK(hipEventSynchronize(ev[n]));
@@ -233,5 +427,6 @@ int main() {
     }
     printf("\n");
   }
+#endif
   return 0;
 }
