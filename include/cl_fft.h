@@ -20,8 +20,16 @@ class Clcfft {
  protected:
   int N;
   bool forward;
-  clfa_fft *plan;   // replaces the reference's context / queue / program / buffers
+  clfa_fft *plan;   // replaces the reference's context / program / kernels
   int cl_err;
+  // The reference's device members a subclass may touch (cl_fft.h:35-37), as HIP objects (cl_compat.h: cl_mem = device
+  // pointer, cl_command_queue = hipStream_t; clEnqueueWriteBuffer / clEnqueueReadBuffer / clFinish work on them):
+  // w = N twiddles, b = N bit reversals (cl_fft.cpp:86-104), data1 / data2 = N complex numbers each, commands = the
+  // object's stream.  They exist for the reference's range of sizes (N <= 65536; NULL above).  fft() (cl_fft.h:44,
+  // cl_fft.cpp:138-151) transforms data1 -> data2 on that stream and, like the reference, only enqueues.
+  cl_mem w, b, data1, data2;
+  cl_command_queue commands;
+  int fft();
 
  public:
   /** device_id - device handle; size - DFT size (N); fwd - direction */
@@ -33,12 +41,15 @@ class Clcfft {
   int transform(std::complex<float> *c, long batch);
   /** device-resident extension: in place on device memory, asynchronous on a hipStream_t */
   int transform_device(void *data, long batch, void *stream = 0);
+  /** ... from src to dst (the reference's device side is out of place too: data1 -> data2) */
+  int transform_device(const void *src, void *dst, long batch, void *stream);
   /** Get setup error code */
   int get_error() { return cl_err; }
   /** Get compilation log (setup diagnostics here; nothing is JIT-compiled) */
   const char *get_log();
 
  private:
+  // not copyable (the reference's implicit copy would double-release its OpenCL handles; here it is ruled out)
   Clcfft(const Clcfft &);
   Clcfft &operator=(const Clcfft &);
 

@@ -112,6 +112,21 @@ CLFA_API int clfa_fft_exec_dev(clfa_fft *plan, void *data, long batch, void *str
  * place (correct, one more pass).  src == dst is clfa_fft_exec_dev; partly overlapping buffers are CLFA_INVALID_VALUE.
  * `src` is left untouched. */
 CLFA_API int clfa_fft_exec_dev_oop(clfa_fft *plan, const void *src, void *dst, long batch, void *stream);
+/* The reference's protected members for subclasses (cl_fft.h:35-44): data1 / data2 = the object's own device buffers of one
+ * transform each (n complex64; real plans: size floats), allocated on first request and released with the plan;
+ * commands = the plan's hipStream_t (the reference's cl_command_queue). */
+CLFA_API int clfa_fft_device_buffers(clfa_fft *plan, void **data1, void **data2, void **commands);
+/* ... and its tables (cl_fft.h:35; cl_fft.cpp:86-104): w = n complex64 twiddles of the plan's direction, b = n int32
+ * bit reversals (c2c plans of the reference's range only, n <= 65536), device copies made on first request */
+CLFA_API int clfa_fft_device_tables(clfa_fft *plan, void **w, void **b);
+/* clEnqueueWriteBuffer / clEnqueueReadBuffer / clFinish as the reference uses them on its queue (cl_fft.cpp:155-158):
+ * host <-> device copies on a hipStream_t (NULL: the default stream), blocking or not */
+CLFA_API int clfa_copy_to_device(void *stream, void *dst, const void *src, size_t bytes, int blocking);
+CLFA_API int clfa_copy_from_device(void *stream, void *dst, const void *src, size_t bytes, int blocking);
+CLFA_API int clfa_stream_synchronize(void *stream);
+/* Clcfft::fft(), cl_fft.cpp:138-151: one transform data1 -> data2 on the plan's stream; like the reference it only
+ * enqueues (synchronise the stream before reading data2).  Real plans run their whole r2c / c2r. */
+CLFA_API int clfa_fft_run_buffers(clfa_fft *plan);
 /* bytes of device workspace a plan holds (0 for single-pass sizes) */
 CLFA_API size_t clfa_fft_workspace_bytes(const clfa_fft *plan);
 /* name of the HIP kernel that does the work for this plan (for profiles) */

@@ -2,7 +2,10 @@
  * (test_cfft.cpp:24-40, csound/opcode.cpp:50-64), mapped onto HIP device ordinals.
  *
  * Not an OpenCL implementation: only device enumeration, the device name query,
- * the scalar typedefs and the status codes.  A cl_device_id is an opaque handle
+ * the scalar typedefs and the status codes — and, for SUBCLASSES of the reference's
+ * classes (they reach the protected members commands / data1 / data2 / w / b,
+ * cl_fft.h:35-44, with clEnqueueWriteBuffer / clEnqueueReadBuffer / clFinish as
+ * cl_fft.cpp:155-158 does), those three calls on a hipStream_t and device pointers.  A cl_device_id is an opaque handle
  * that encodes "HIP ordinal + 1"; it is only meaningful to the classes in
  * cl_fft.h / cl_conv.h / cl_dconv.h of this package.
  *
@@ -31,6 +34,12 @@ typedef struct _cl_platform_id *cl_platform_id;
 typedef struct _cl_device_id *cl_device_id;
 typedef float cl_float;
 typedef struct { float s[2]; } cl_float2;
+typedef cl_uint cl_bool;
+typedef void *cl_mem;             /* a device pointer */
+typedef void *cl_command_queue;   /* a hipStream_t */
+typedef struct _cl_event *cl_event;
+#define CL_TRUE 1
+#define CL_FALSE 0
 
 #define CL_SUCCESS 0
 #define CL_DEVICE_NOT_FOUND -1
@@ -76,8 +85,23 @@ static inline cl_int clfa_clGetDeviceInfo(cl_device_id id, cl_device_info what, 
   return e;
 }
 #ifdef CLFA_DEFINED_CL_TYPES
+/* cl_fft.cpp:155 / :158 / cl_conv.cpp:38-41: copies on the object's queue, events ignored (none are ever passed) */
+static inline cl_int clfa_clEnqueueWriteBuffer(cl_command_queue q, cl_mem buf, cl_bool blocking, size_t off, size_t bytes,
+                                                const void *ptr, cl_uint nev, const cl_event *wait, cl_event *ev) {
+  (void)nev; (void)wait; (void)ev;
+  return clfa_copy_to_device(q, (char *)buf + off, ptr, bytes, (int)blocking);
+}
+static inline cl_int clfa_clEnqueueReadBuffer(cl_command_queue q, cl_mem buf, cl_bool blocking, size_t off, size_t bytes,
+                                               void *ptr, cl_uint nev, const cl_event *wait, cl_event *ev) {
+  (void)nev; (void)wait; (void)ev;
+  return clfa_copy_from_device(q, ptr, (const char *)buf + off, bytes, (int)blocking);
+}
+static inline cl_int clfa_clFinish(cl_command_queue q) { return clfa_stream_synchronize(q); }
 #define clGetDeviceIDs clfa_clGetDeviceIDs
 #define clGetDeviceInfo clfa_clGetDeviceInfo
+#define clEnqueueWriteBuffer clfa_clEnqueueWriteBuffer
+#define clEnqueueReadBuffer clfa_clEnqueueReadBuffer
+#define clFinish clfa_clFinish
 #endif
 #endif /* CLFA_NO_CL_SHIM */
 

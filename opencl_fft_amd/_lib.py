@@ -33,6 +33,12 @@ SYMBOLS = [
     ("clfa_rfft_transform", C.c_int, [_vp, _vp, _vp, C.c_long]),
     ("clfa_fft_exec_dev", C.c_int, [_vp, _vp, C.c_long, _vp]),
     ("clfa_fft_exec_dev_oop", C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
+    ("clfa_fft_device_buffers", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    ("clfa_fft_run_buffers", C.c_int, [_vp]),
+    ("clfa_fft_device_tables", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    ("clfa_copy_to_device", C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int]),
+    ("clfa_copy_from_device", C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int]),
+    ("clfa_stream_synchronize", C.c_int, [_vp]),
     ("clfa_fft_workspace_bytes", C.c_size_t, [_vp]),
     ("clfa_fft_kernel_name", C.c_char_p, [_vp]),
     ("clfa_reorder_dev", C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_long, _vp]),

@@ -8,13 +8,24 @@ namespace cl_fft {
 const char *cl_error_string(int err) { return clfa_error_string(err); }   // cl_fft.cpp:298-395
 
 // Clcfft::Clcfft, cl_fft.cpp:44-125
-Clcfft::Clcfft(cl_device_id device_id, int size, bool fwd) : N(size), forward(fwd), plan(NULL), cl_err(0) {
+Clcfft::Clcfft(cl_device_id device_id, int size, bool fwd)
+    : N(size), forward(fwd), plan(NULL), cl_err(0), w(NULL), b(NULL), data1(NULL), data2(NULL), commands(NULL) {
   cl_err = clfa_cfft_create(&plan, clfa_device_ordinal(device_id), size, fwd ? 1 : 0);
+  if (!cl_err && size <= 65536 && !(size & (size - 1))) {   // the reference's range: its protected members exist
+    clfa_fft_device_buffers(plan, &data1, &data2, &commands);
+    clfa_fft_device_tables(plan, &w, &b);
+  }
 }
 // Clrfft constructs its base with size/2 (cl_fft.cpp:210): the member N is M = size/2
-Clcfft::Clcfft(cl_device_id device_id, int size, bool fwd, bool) : N(size / 2), forward(fwd), plan(NULL), cl_err(0) {
+Clcfft::Clcfft(cl_device_id device_id, int size, bool fwd, bool)
+    : N(size / 2), forward(fwd), plan(NULL), cl_err(0), w(NULL), b(NULL), data1(NULL), data2(NULL), commands(NULL) {
   cl_err = clfa_rfft_create(&plan, clfa_device_ordinal(device_id), size, fwd ? 1 : 0);
+  if (!cl_err && size <= 131072 && !(size & (size - 1))) {
+    clfa_fft_device_buffers(plan, &data1, &data2, &commands);
+    clfa_fft_device_tables(plan, &w, &b);
+  }
 }
+int Clcfft::fft() { return clfa_fft_run_buffers(plan); }                   // cl_fft.cpp:138-151
 Clcfft::~Clcfft() { clfa_fft_destroy(plan); }                              // cl_fft.cpp:127-136
 int Clcfft::transform(std::complex<float> *c) {                             // cl_fft.cpp:153-161
   return clfa_cfft_transform(plan, reinterpret_cast<float *>(c), 1);
@@ -23,6 +34,9 @@ int Clcfft::transform(std::complex<float> *c, long batch) {
   return clfa_cfft_transform(plan, reinterpret_cast<float *>(c), batch);
 }
 int Clcfft::transform_device(void *data, long batch, void *stream) { return clfa_fft_exec_dev(plan, data, batch, stream); }
+int Clcfft::transform_device(const void *src, void *dst, long batch, void *stream) {
+  return clfa_fft_exec_dev_oop(plan, src, dst, batch, stream);
+}
 const char *Clcfft::get_log() { return clfa_fft_get_log(plan); }
 
 Clrfft::Clrfft(cl_device_id device_id, int size, bool fwd) : Clcfft(device_id, size, fwd, true) {}   // cl_fft.cpp:208-259

@@ -258,6 +258,8 @@ struct clfa_fft {
   char log[2048];
   hipStream_t stream = nullptr;
   DevBuf half, w2, four, scratch, stage, res16;
+  DevBuf own1, own2;     // the reference's protected data1 / data2 (cl_fft.h:35), on request: clfa_fft_device_buffers
+  DevBuf own_w, own_b;   // ... and w / b: clfa_fft_device_tables
   StreamOrder order;
   HostBuf zstage;        // zero-copy staging of small host transforms
   FftTables tabs;
@@ -665,6 +667,10 @@ void clfa_fft_destroy(clfa_fft *p) {
   p->four.release();
   p->scratch.release();
   p->stage.release();
+  p->own1.release();
+  p->own2.release();
+  p->own_w.release();
+  p->own_b.release();
   p->res16.release();
   p->zstage.release();
   p->bigtabs.release();
@@ -785,6 +791,66 @@ int clfa_fft_exec_dev_oop(clfa_fft *p, const void *src, void *dst, long batch, v
   }
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
   return clfa_fft_exec_dev(p, dst, batch, stream);
+}
+
+int clfa_fft_device_buffers(clfa_fft *p, void **data1, void **data2, void **commands) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  ENTER_DEVICE(p->di.device);
+  const size_t bytes = sizeof(cpx) * (size_t)p->n;
+  int e = p->own1.ensure(bytes);
+  if (!e) e = p->own2.ensure(bytes);
+  if (e) return e;
+  if (data1) *data1 = p->own1.p;
+  if (data2) *data2 = p->own2.p;
+  if (commands) *commands = (void *)p->stream;
+  return CLFA_SUCCESS;
+}
+
+int clfa_fft_device_tables(clfa_fft *p, void **w, void **b) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (p->blue_m || p->logn < 1 || p->logn > kMaxLog) return CLFA_INVALID_OPERATION;
+  ENTER_DEVICE(p->di.device);
+  const int n = p->n;
+  if (!p->own_w.p) {
+    std::vector<cpx> tw;
+    fill_twiddle(tw, n, n, 1, p->fwd ? -1.f : 1.f);                 // cl_fft.cpp:86-91
+    std::vector<int> br((size_t)n);
+    int e = clfa_bitrev_table(n, br.data());                        // cl_fft.cpp:96-101
+    if (!e) e = p->own_w.ensure(sizeof(cpx) * (size_t)n);
+    if (!e) e = p->own_b.ensure(sizeof(int) * (size_t)n);
+    if (e) return e;
+    HIP_TRY(hipMemcpy(p->own_w.p, tw.data(), sizeof(cpx) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->own_b.p, br.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  }
+  if (w) *w = p->own_w.p;
+  if (b) *b = p->own_b.p;
+  return CLFA_SUCCESS;
+}
+
+int clfa_copy_to_device(void *stream, void *dst, const void *src, size_t bytes, int blocking) {
+  if ((!dst || !src) && bytes) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  if (blocking) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return CLFA_SUCCESS;
+}
+int clfa_copy_from_device(void *stream, void *dst, const void *src, size_t bytes, int blocking) {
+  if ((!dst || !src) && bytes) return CLFA_INVALID_VALUE;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (blocking) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return CLFA_SUCCESS;
+}
+int clfa_stream_synchronize(void *stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return CLFA_SUCCESS;
+}
+
+int clfa_fft_run_buffers(clfa_fft *p) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!p->own1.p || !p->own2.p) return CLFA_INVALID_MEM_OBJECT;
+  return clfa_fft_exec_dev_oop(p, p->own1.p, p->own2.p, 1, p->stream);
 }
 
 // bytes per call up to which the host entry points go zero-copy: the kernels read the input from,
@@ -1025,29 +1091,44 @@ int clfa_pconv_push_ir(clfa_pconv *p, const float *ir) {
   return CLFA_SUCCESS;
 }
 
+// [a, a + n) and [b, b + n) share a byte
+static bool ranges_overlap(const void *a, const void *b, size_t n) {
+  const char *x = (const char *)a, *y = (const char *)b;
+  return x < y + n && y < x + n;
+}
+
 int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void *in2, void *stream) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!out || !in1) return CLFA_INVALID_VALUE;
+  {
+    // the kernels read the inputs of ALL channels while workgroups of other channels may already write their output
+    // (the buffers are __restrict__): any overlap of out with an input — not only equal pointers — is refused
+    const size_t blk = sizeof(float) * (size_t)p->pts * (size_t)p->g.channels;
+    if (ranges_overlap(out, in1, blk) || (in2 && ranges_overlap(out, in2, blk))) return CLFA_INVALID_VALUE;
+  }
   ENTER_DEVICE(p->di.device);
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(p->order.use(s));
   int e;
   if (p->fused || p->coop.logs >= 0) {
-    // whole block in one launch; ring indices advance exactly as below
+    // whole block in one launch; ring indices advance exactly as below — committed only once the launch has been accepted
+    // (a rejected launch must not skew the host's ring position against the device's rings)
     const int frame1 = p->wp, frame2 = p->wp2;
-    p->wp = p->wp != p->g.nparts - 1 ? p->wp + 1 : 0;
-    if (in2) p->wp2 = p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1;
+    const int wp_next = p->wp != p->g.nparts - 1 ? p->wp + 1 : 0;
+    const int wp2_next = in2 ? (p->wp2 == 0 ? p->g.nparts - 1 : p->wp2 - 1) : p->wp2;
     if (!p->fused) {
       HIP_TRY(launch_pconv_coop(p->g, p->coop, (const float *)in1, (const float *)in2, (cpx *)p->ringA.p,
-                                (cpx *)p->ringB.p, (float *)p->tail.p, (float *)out, frame1, frame2, p->wp,
+                                (cpx *)p->ringB.p, (float *)p->tail.p, (float *)out, frame1, frame2, wp_next,
                                 (const cpx *)p->half.p, (const cpx *)p->w2f.p, (const cpx *)p->w2i.p, (cpx *)p->acc.p,
-                                (unsigned *)p->cnt.p, s));
-      return CLFA_SUCCESS;
+                                (unsigned *)p->cnt.p, p->di.num_cus, s));
+    } else {
+      HIP_TRY(launch_pconv_fused(p->g, (const float *)in1, (const float *)in2, (cpx *)p->ringA.p, (cpx *)p->ringB.p,
+                                 (float *)p->tail.p, (float *)out, frame1, frame2, wp_next, (const cpx *)p->half.p,
+                                 (const cpx *)p->w2f.p, (const cpx *)p->w2i.p, s, p->g.channels < p->di.num_cus));
     }
-    HIP_TRY(launch_pconv_fused(p->g, (const float *)in1, (const float *)in2, (cpx *)p->ringA.p, (cpx *)p->ringB.p,
-                               (float *)p->tail.p, (float *)out, frame1, frame2, p->wp, (const cpx *)p->half.p,
-                               (const cpx *)p->w2f.p, (const cpx *)p->w2i.p, s, p->g.channels < p->di.num_cus));
+    p->wp = wp_next;
+    p->wp2 = wp2_next;
     return CLFA_SUCCESS;
   }
   const bool lds = p->g.logb <= kLdsMaxLog;
@@ -1177,9 +1258,9 @@ int clfa_dconv_push_ir(clfa_dconv *d, const float *ir) {
 // outputs — all in ONE launch (conv_kernels.hip, k_dconv_block)
 static int dconv_block(clfa_dconv *d, float *out, const float *in1, const float *in2, hipStream_t s) {
   const int wp = d->wp;
-  d->wp = (d->wp + d->vsize) % (d->irsize + d->vsize);
   HIP_TRY(launch_dconv_block(d->plan, out, in1, in2, (float *)d->del.p, (float *)d->coefs.p, (float *)d->part.p,
-                             (unsigned *)d->cnt.p, d->irsize, d->vsize, wp, s));
+                             (unsigned *)d->cnt.p, d->irsize, d->vsize, wp, d->di.num_cus, s));
+  d->wp = (wp + d->vsize) % (d->irsize + d->vsize);   // committed only once the launch has been accepted
   return CLFA_SUCCESS;
 }
 
@@ -1224,7 +1305,10 @@ int clfa_dconv_convolution_tv(clfa_dconv *d, float *out, const float *in1, const
 int clfa_dconv_process_dev(clfa_dconv *d, void *out, const void *in1, const void *in2, void *stream) {
   if (!d) return CLFA_INVALID_VALUE;
   if (d->err) return d->err;
-  if (!out || !in1 || out == in1 || out == in2) return CLFA_INVALID_VALUE;
+  if (!out || !in1) return CLFA_INVALID_VALUE;
+  // the last-arriving workgroup writes out while others may still stage their in1 / in2 windows: no overlap at all
+  const size_t blk = sizeof(float) * (size_t)d->vsize;
+  if (ranges_overlap(out, in1, blk) || (in2 && ranges_overlap(out, in2, blk))) return CLFA_INVALID_VALUE;
   ENTER_DEVICE(d->di.device);
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(d->order.use(s));

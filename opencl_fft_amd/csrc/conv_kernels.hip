@@ -578,6 +578,22 @@ hipError_t launch_pconv_fused(const PconvGeom &g, const float *in1, const float 
 // storing wave s_waitcnt vmcnt(0), workgroup barrier, ONE lane's agent-scope atomic add on the channel's counter;
 // the workgroup whose add returns S - 1 reads every slice with agent-scope (sc1) loads after its own barrier.
 // ---------------------------------------------------------------------------------
+// The hand-overs below are written for gfx950's memory pipeline (sc1 stores write through, vmcnt counts stores, sc1 loads
+// are served past the CU's L1): another target needs the C++ release / acquire forms instead.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "conv_kernels.hip: the inter-workgroup hand-overs are gfx950-specific (see MI355X_MICROARCH.md, 'Valid forms')"
+#endif
+// The form without an acquire is the one MI355X_MICROARCH.md measured ("Valid forms": sc1 stores, every storing wave's
+// vmcnt(0), barrier, one lane's agent-scope add; the workgroup whose add came last loads with sc1 loads) — for launches of
+// at most ONE workgroup per CU.  A launch with more workgroups than CUs (acquire != 0, set by the launcher) is outside
+// that table: there the arriving lane of the last workgroup runs the documented consumer form as well — one agent-scope
+// acquire (buffer_inv sc1) and its wait, in front of the barrier that releases the other waves' loads.
+__device__ __forceinline__ void handover_acquire(int acquire) {
+  if (acquire) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
 __device__ __forceinline__ void st_agent(cpx *p, cpx v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
@@ -594,7 +610,7 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
                                                     int frame2, int wp, int nparts, const cpx *__restrict__ tab_g,
                                                     const cpx *__restrict__ w2f_g, const cpx *__restrict__ w2i_g,
                                                     cpx *__restrict__ xacc, unsigned *__restrict__ counters, int logs,
-                                                    int sparts) {
+                                                    int sparts, int acquire) {
   using G = LdsGeom<LOGB>;
   constexpr int N = G::N, E = G::E, T = G::T, HB = N / 2;   // N = bins; T = N/16 lanes run the FFTs
   constexpr int WG = G::WG;                                  // 256 lanes; 512 for partitions of 8192 samples
@@ -825,7 +841,10 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
   if (tid == 0) {
     const unsigned old = __hip_atomic_fetch_add(counters + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = old == (unsigned)(S * sparts - 1);
-    if (s_last) __hip_atomic_store(counters + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch
+    if (s_last) {
+      __hip_atomic_store(counters + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch
+      handover_acquire(acquire);
+    }
   }
   __syncthreads();
   if (!s_last) return;
@@ -901,14 +920,12 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
 
 // Shape of the cooperative block, or logs = -1 when it does not apply: bins 32..4096; slices of 32 bins (256-byte
 // segments of a frame) unless the channels alone would overfill the chip; the partition axis cut into segments until
-// a workgroup's share of the two rings is at most CLFA_PCONV_COOP_MAX_KB (tuning switch, read once; 0 switches the
+// a workgroup's share of the two rings is at most CLFA_PCONV_COOP_MAX_KB (tuning switch, read at plan creation; 0 switches the
 // kernel off); filters that would need more than half the CUs that way stay with the launch chain above (the split
 // MAC + tree sum), which puts the whole chip on the partition axis.
 PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di) {
-  static const long cap_kb = [] {
-    const char *e = getenv("CLFA_PCONV_COOP_MAX_KB");
-    return e ? atol(e) : 128L;
-  }();
+  const char *cap_env = getenv("CLFA_PCONV_COOP_MAX_KB");   // read per plan, like every other tuning switch
+  const long cap_kb = cap_env ? atol(cap_env) : 128L;
   PconvCoop c{-1, 1};
   // (partitions of 8192 samples were measured on this kernel with 512-lane workgroups: 27 us static, 36 us time-varying
   // against 29 us on the chain — a workgroup's own 8192-point transforms take 10 us each — so they stay on the chain)
@@ -944,24 +961,25 @@ PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di) {
 template <int LOGB>
 static hipError_t launch_coop_one(const PconvGeom &g, PconvCoop c, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                                   float *tail, float *out, int frame1, int frame2, int wp, const cpx *half, const cpx *w2f,
-                                  const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s) {
+                                  const cpx *w2i, cpx *xacc, unsigned *counters, int num_cus, hipStream_t s) {
   const dim3 grid(c.sparts << c.logs, g.channels);
+  const int acquire = (long)grid.x * grid.y > num_cus;   // more workgroups than CUs: see handover_acquire()
   if (in2)
     hipLaunchKernelGGL((k_pconv_coop<LOGB, true>), grid, dim3(LdsGeom<LOGB>::WG), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
-                       wp, g.nparts, half, w2f, w2i, xacc, counters, c.logs, c.sparts);
+                       wp, g.nparts, half, w2f, w2i, xacc, counters, c.logs, c.sparts, acquire);
   else
     hipLaunchKernelGGL((k_pconv_coop<LOGB, false>), grid, dim3(LdsGeom<LOGB>::WG), 0, s, in1, in2, ringA, ringB, tail, out, frame1, frame2,
-                       wp, g.nparts, half, w2f, w2i, xacc, counters, c.logs, c.sparts);
+                       wp, g.nparts, half, w2f, w2i, xacc, counters, c.logs, c.sparts, acquire);
   return hipGetLastError();
 }
 
 hipError_t launch_pconv_coop(const PconvGeom &g, PconvCoop c, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                              float *tail, float *out, int frame1, int frame2, int wp, const cpx *half, const cpx *w2f,
-                             const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s) {
+                             const cpx *w2i, cpx *xacc, unsigned *counters, int num_cus, hipStream_t s) {
   switch (g.logb) {
 #define CLFA_B(L) \
   case L:         \
-    return launch_coop_one<L>(g, c, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, xacc, counters, s);
+    return launch_coop_one<L>(g, c, in1, in2, ringA, ringB, tail, out, frame1, frame2, wp, half, w2f, w2i, xacc, counters, num_cus, s);
     CLFA_B(5) CLFA_B(6) CLFA_B(7) CLFA_B(8) CLFA_B(9) CLFA_B(10) CLFA_B(11) CLFA_B(12)
 #undef CLFA_B
     default:
@@ -1050,7 +1068,8 @@ __device__ __forceinline__ float ld_agent_f(const float *p) {
 __global__ __launch_bounds__(256) void k_dconv_block(float *__restrict__ out, const float *__restrict__ in1,
                                                      const float *__restrict__ in2, float *__restrict__ del,
                                                      float *__restrict__ coefs, float *__restrict__ part,
-                                                     unsigned *__restrict__ counters, int irsize, int vsize, int wp, int C) {
+                                                     unsigned *__restrict__ counters, int irsize, int vsize, int wp, int C,
+                                                     int acquire) {
   __shared__ float s_k[kDconvMaxC];
   __shared__ float s_d[kDconvMaxC + kDconvNT];
   __shared__ float s_red[256];
@@ -1132,7 +1151,10 @@ __global__ __launch_bounds__(256) void k_dconv_block(float *__restrict__ out, co
   if (tid == 0) {
     const unsigned old = __hip_atomic_fetch_add(counters + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = old == (unsigned)(G - 1);
-    if (s_last) __hip_atomic_store(counters + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch
+    if (s_last) {
+      __hip_atomic_store(counters + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch
+      handover_acquire(acquire);
+    }
   }
   __syncthreads();
   if (!s_last) return;
@@ -1163,11 +1185,11 @@ __global__ __launch_bounds__(256) void k_dconv_block(float *__restrict__ out, co
 }
 
 hipError_t launch_dconv_block(const DconvPlan &pl, float *out, const float *in1, const float *in2, float *del, float *coefs,
-                              float *part, unsigned *counters, int irsize, int vsize, int wp, hipStream_t s) {
+                              float *part, unsigned *counters, int irsize, int vsize, int wp, int num_cus, hipStream_t s) {
   if (pl.C < 1 || pl.C > kDconvMaxC || pl.G < 1 || (long)pl.C * pl.G < irsize || pl.VB < 1 || pl.VB > kDconvMaxVB)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_dconv_block, dim3(pl.G, pl.VB), dim3(256), 0, s, out, in1, in2, del, coefs, part, counters, irsize,
-                     vsize, wp, pl.C);
+                     vsize, wp, pl.C, (long)pl.G * pl.VB > num_cus ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -134,7 +134,7 @@ struct PconvCoop {
 PconvCoop pconv_coop_plan(const PconvGeom &g, const DeviceInfo &di);
 hipError_t launch_pconv_coop(const PconvGeom &g, PconvCoop c, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
                              float *tail, float *out, int frame1, int frame2, int wp, const cpx *half, const cpx *w2f,
-                             const cpx *w2i, cpx *xacc, unsigned *counters, hipStream_t s);
+                             const cpx *w2i, cpx *xacc, unsigned *counters, int num_cus, hipStream_t s);
 // pconv_fused_ok(): bins 512..4096 and enough channels to fill the chip
 bool pconv_fused_ok(const PconvGeom &g, const DeviceInfo &di);
 hipError_t launch_pconv_fused(const PconvGeom &g, const float *in1, const float *in2, cpx *ringA, cpx *ringB,
@@ -155,6 +155,6 @@ DconvPlan dconv_plan(int irsize, int vsize);
 // one block: out[0..vsize) from the rings as they stand with in1 (and in2) written at wp; files the block in the rings.
 // part: G x vsize floats, counters: VB zeroed words (both only touched when G > 1).  out must not overlap in1 / in2.
 hipError_t launch_dconv_block(const DconvPlan &pl, float *out, const float *in1, const float *in2, float *del, float *coefs,
-                              float *part, unsigned *counter, int irsize, int vsize, int wp, hipStream_t s);
+                              float *part, unsigned *counter, int irsize, int vsize, int wp, int num_cus, hipStream_t s);
 
 }  // namespace clfa

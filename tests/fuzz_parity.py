@@ -1,5 +1,5 @@
-"""Randomised parity sweep on the GPU box (not collected by pytest; run as a script):
-    python tests/fuzz_parity.py [seconds] [seed]
+"""Randomised parity sweep on the GPU box: `python tests/fuzz_parity.py [seconds] [seed]`, and — with a fixed seed and a
+bounded budget — a `-m gpu` test (tests/test_gpu_misc.py::test_randomised_parity_sweep calls run()).
 Random geometries of every object of the path — complex and packed real plans (powers of two with ragged batches, a
 few other lengths), partitioned convolutions (channels, partitions, static / time-varying, host and device entry
 points), direct convolutions — each checked against the CPU oracle (numpy fp64 for the lengths the reference does not
@@ -17,19 +17,19 @@ import opencl_fft_amd as fa  # noqa: E402
 from oracle import oracle  # noqa: E402
 from tests.util import rel_err  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
+rng = np.random.default_rng(1)
 counts = {}
+quiet = False
 
 
 def check(kind, desc, got, want, tol):
     l2, mx = rel_err(got, want)
     counts[kind] = counts.get(kind, 0) + 1
     ok = l2 <= tol and mx <= tol
-    print("%-6s %-62s relL2 %.2e max %.2e %s" % (kind, desc, l2, mx, "" if ok else "FAIL (tol %.1e)" % tol), flush=True)
-    if not ok:
-        sys.exit(1)
+    line = "%-6s %-62s relL2 %.2e max %.2e %s" % (kind, desc, l2, mx, "" if ok else "FAIL (tol %.1e)" % tol)
+    if not quiet or not ok:
+        print(line, flush=True)
+    assert ok, line
 
 
 def sym(shape):
@@ -46,7 +46,15 @@ def case_cfft():
     p = fa.Clcfft(0, n, fwd)
     assert p.get_error() == 0, p.get_log()
     d = torch.from_numpy(x.view(np.float32).reshape(batch, n, 2).copy()).cuda()
-    assert p.exec_device(d, batch) == 0
+    oop = bool(rng.integers(0, 3) == 0)          # a third of the cases through the out-of-place entry point
+    if oop:
+        dst = torch.full_like(d, float("nan"))
+        assert p.exec_device_oop(d, dst, batch) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), x.view(np.uint32).reshape(batch, n, 2)), "source modified"
+        d = dst
+    else:
+        assert p.exec_device(d, batch) == 0
     torch.cuda.synchronize()
     got = d.cpu().numpy().view(np.complex64).reshape(batch, n)
     pick = sorted(set([0, batch - 1, batch // 2] + [int(v) for v in rng.integers(0, batch, 3)]))
@@ -54,7 +62,7 @@ def case_cfft():
         want = oracle.cfft(x[pick], fwd)
     else:   # beyond the reference's range: numpy fp64 with the reference's scaling
         want = (np.fft.fft(x[pick].astype(np.complex128)) / n) if fwd else np.fft.ifft(x[pick].astype(np.complex128)) * n
-    check("cfft", "n=2^%d batch=%d %s kernel=%s" % (logn, batch, "fwd" if fwd else "inv", p.kernel_name()), got[pick], want, 1e-6)
+    check("cfft", "n=2^%d batch=%d %s%s kernel=%s" % (logn, batch, "fwd" if fwd else "inv", " oop" if oop else "", p.kernel_name()), got[pick], want, 1e-6)
 
 
 def case_cfft_any():
@@ -169,9 +177,23 @@ def case_dconv():
 
 
 cases = [case_cfft, case_cfft, case_rfft, case_rfft, case_pconv, case_pconv, case_pconv, case_dconv, case_dconv, case_cfft_any]
-t0 = time.time()
-k = 0
-while time.time() - t0 < budget:
-    cases[k % len(cases)]()
-    k += 1
-print("fuzz ok: %d cases in %.0f s (seed %d): %s" % (k, time.time() - t0, seed, counts))
+
+
+def run(budget, seed, silent=False):
+    """random cases of all five object kinds until `budget` seconds are spent; AssertionError on the first failure;
+    -> (number of cases, per-kind counts)"""
+    global rng, quiet
+    rng = np.random.default_rng(seed)
+    quiet = silent
+    counts.clear()
+    t0 = time.time()
+    k = 0
+    while time.time() - t0 < budget:
+        cases[k % len(cases)]()
+        k += 1
+    print("fuzz ok: %d cases in %.0f s (seed %d): %s" % (k, time.time() - t0, seed, counts))
+    return k, dict(counts)
+
+
+if __name__ == "__main__":
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)

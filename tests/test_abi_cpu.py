@@ -87,6 +87,40 @@ def test_engine_emulation_on_cpu(tmp_path):
     assert out.strip().endswith("OK"), out
 
 
+def _compile_to_asm(tmp_path, name):
+    src = os.path.join(ROOT, "opencl_fft_amd", "csrc", name + ".hip")
+    flags = None
+    for ln in open(os.path.join(ROOT, "opencl_fft_amd", "csrc", "Makefile")):
+        if ln.startswith("CXXFLAGS"):
+            flags = ln.split("=", 1)[1].replace("$(ARCH)", "gfx950").split()
+    assert flags, "CXXFLAGS not found in the Makefile"
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine: the code-object audit needs the gfx950 cross-compiler")
+    p = subprocess.run([hipcc] + flags + ["-save-temps=obj", "-c", src, "-o", str(tmp_path / (name + ".o"))],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
+    asm = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
+    assert len(asm) == 1, asm
+    return str(tmp_path / asm[0])
+
+
+def _check_isa():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_handover_kernels_code_object_audit(tmp_path):
+    """conv_kernels.hip: the hand-overs of k_pconv_coop / k_dconv_block on the compiled ISA — sc1 stores, agent-scope loads
+    as global_ / buffer_ loads with sc1 (never flat_), an arrival add, and the acquire for launches beyond one workgroup
+    per CU (tools/check_isa.py --handover)"""
+    problems = _check_isa().check_handover(_compile_to_asm(tmp_path, "conv_kernels"))
+    assert not problems, "\n".join(problems[:10])
+
+
 def test_resident_kernel_code_object_audit(tmp_path):
     """fft_resident.hip manages the accumulation registers and v[224:255] by hand; tools/check_isa.py
     verifies on the freshly compiled ISA that hipcc put nothing of its own there and uses no scratch"""

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
-PROGS = ["test_cfft", "test_rfft", "test_conv", "test_opcodes"]
+PROGS = ["test_cfft", "test_rfft", "test_conv", "test_opcodes", "test_subclass"]
 
 
 @pytest.fixture(scope="module")

@@ -218,6 +218,11 @@ def test_dconv_device_resident_blocks_vs_oracle(irsize, vsize, blocks, tv):
     assert (d.convolution(out, x1[sl], x2[sl]) if tv else d.convolution(out, x1[sl])) == 0
     assert_parity(out, o.convolution(x1[sl], x2[sl]) if tv else o.convolution(x1[sl]), tol=tol, what="host call after")
     assert d.process_device(dout[0], dout[0]) == -30   # out must not be an input
+    if vsize >= 4:                                     # ... nor overlap one partly (one caller buffer, out = in + k)
+        buf = torch.zeros(2 * vsize, device="cuda")
+        assert d.process_device(buf[vsize // 2:vsize // 2 + vsize], buf[:vsize]) == -30
+        assert d.process_device(buf[:vsize], buf[vsize // 2:vsize // 2 + vsize]) == -30
+        assert d.process_device(buf[vsize:], buf[:vsize], buf[1:vsize + 1] if tv else None) == (-30 if tv else 0)
 
 
 def test_dconv_handoff_under_load():
@@ -226,7 +231,10 @@ def test_dconv_handoff_under_load():
     stream keeps every CU busy with large transforms — the two runs must agree bit for bit."""
     import torch
     blocks = 120
-    for irsize, vsize, tv in ((96000, 64, False), (70000, 256, True), (300000, 16, False)):
+    # the last geometry launches 256 x 4 workgroups — more than the chip has CUs, where the last workgroup also runs an
+    # agent-scope acquire (conv_kernels.hip, handover_acquire)
+    for irsize, vsize, tv in ((96000, 64, False), (70000, 256, True), (300000, 16, False), (1 << 20, 256, False)):
+        blocks = 120 if irsize < (1 << 20) else 40
         g = torch.Generator(device="cuda").manual_seed(irsize + vsize)
         ir = ((torch.rand(irsize, generator=g, device="cuda") - 0.5) / irsize ** 0.5).cpu().numpy()
         x1 = torch.rand((blocks, vsize), generator=g, device="cuda") * 2 - 1
@@ -452,7 +460,11 @@ def test_pconv_cooperative_handoff_under_load():
     their CUs.  The summation order is fixed, so the two runs must agree bit for bit in every output word."""
     import torch
     blocks = 200
-    for pts, nparts, channels, tv in ((512, 128, 1, False), (1024, 94, 3, True), (256, 600, 1, False)):
+    # the last two geometries launch MORE workgroups than the chip has CUs (136 channels x 2 bin slices = 272; 100 x 4 =
+    # 400): there the last workgroup also runs an agent-scope acquire (conv_kernels.hip, handover_acquire)
+    for pts, nparts, channels, tv in ((512, 128, 1, False), (1024, 94, 3, True), (256, 600, 1, False), (1024, 94, 136, False),
+                                      (2048, 24, 100, True)):
+        blocks = 200 if channels < 100 else 60
         g = torch.Generator(device="cuda").manual_seed(pts + nparts)
         ir = (torch.rand((channels, pts * nparts), generator=g, device="cuda") - 0.5) / (pts * nparts) ** 0.5
         x1 = torch.rand((blocks, channels, pts), generator=g, device="cuda") * 2 - 1
@@ -475,9 +487,10 @@ def test_pconv_cooperative_handoff_under_load():
             torch.cuda.synchronize()
             outs.append(y)
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (pts, nparts, channels, tv)
-        o = oracle.Pconv(pts * nparts, pts)
-        if not tv:
-            o.push_ir(ir[0].cpu().numpy())
-        xs1, xs2 = x1[:, 0].cpu().numpy(), x2[:, 0].cpu().numpy()
-        want = np.stack([o.convolution(xs1[b], xs2[b] if tv else None) for b in range(12)])
-        assert_parity(outs[1][:12, 0].cpu().numpy(), want, tol=CTOL, what="first blocks vs oracle")
+        for c in sorted({0, channels - 1}):
+            o = oracle.Pconv(pts * nparts, pts)
+            if not tv:
+                o.push_ir(ir[c].cpu().numpy())
+            xs1, xs2 = x1[:, c].cpu().numpy(), x2[:, c].cpu().numpy()
+            want = np.stack([o.convolution(xs1[b], xs2[b] if tv else None) for b in range(12)])
+            assert_parity(outs[1][:12, c].cpu().numpy(), want, tol=CTOL, what="first blocks of channel %d vs oracle" % c)

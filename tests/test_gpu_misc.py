@@ -103,6 +103,13 @@ def test_bench_two_rank_rehearsal():
     # whole-job value = samples of BOTH ranks over the max time
     expect = 2 * 256 * 65536 * 4 / (r["ms_per_step"] * 4 * 1e-3) / 1e9
     assert abs(r["value"] - expect) / expect < 1e-6
+    # the N > 1 line describes itself: every rank's own figures, the world size the process group reports
+    c = r["config"]
+    assert c["rccl_world_size"] == 2 and c["backend"] == "gloo"
+    assert len(c["per_gpu_gsamples"]) == 2 and all(v > 0 for v in c["per_gpu_gsamples"])
+    assert [q["rank"] for q in c["per_rank"]] == [0, 1] and [q["shard_start"] for q in c["per_rank"]] == [0, 256]
+    assert all(q["kernel"] == "k_fft_res16" and q["device"] and q["batch"] == 256 for q in c["per_rank"])
+    assert r["value"] <= sum(c["per_gpu_gsamples"]) * (1 + 1e-9)      # whole job = all samples over the SLOWEST rank's time
 
 
 def test_bench_starts_its_own_ranks():
@@ -118,6 +125,15 @@ def test_bench_starts_its_own_ranks():
     r = json.loads(line[0])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 512 and r["cpu_baseline"] is None
     assert "other_workloads" not in r["config"] and r["ms_per_step_cold"] > 0
+
+
+def test_randomised_parity_sweep():
+    """tests/fuzz_parity.py with a fixed seed and a bounded budget: random geometries of all five object kinds (complex and
+    packed real plans incl. the out-of-place entry point, partitioned / time-varying / direct convolution, host and device
+    entry points), every case against the oracle"""
+    from tests import fuzz_parity
+    cases, counts = fuzz_parity.run(45.0, 20261004, silent=True)
+    assert cases >= 20 and set(counts) >= {"cfft", "rfft", "pconv", "dconv", "any"}, counts
 
 
 def test_bench_default_line_carries_every_single_gpu_config():
@@ -139,6 +155,13 @@ def test_bench_default_line_carries_every_single_gpu_config():
     assert ow["pconv"]["realtime_ratio"] > 50 and "BASELINE configs[3]" in ow["pconv"]["workload"]
     assert "BASELINE configs[2]" in ow["rfft"]["workload"] and ow["rfft"]["full_size_selfcheck"]["roundtrip_max_abs"] < 2e-5
     assert r["cpu_baseline"]["kind"] == "port"
+    for k in ("rfft", "pconv"):       # every leg against its own CPU restatement
+        assert ow[k]["cpu_baseline"]["kind"] == "port" and ow[k]["cpu_baseline"]["value"] > 0 and ow[k]["cpu_baseline"]["cores"] >= 1
+    oop = r["config"]["out_of_place"]       # the same transforms through the out-of-place entry point, never the headline
+    assert oop["steps"] % 2 == 0 and 0 < oop["roofline"]["frac"] < 1 and oop["roofline"]["kernel"] == "k_fft_res16"
+    assert "in place" in r["config"]["workload"] and r["config"]["library"].endswith("libclfft_amd.so")
+    ref = r["reference_opencl_same_gpu"]
+    assert ref["kind"] == "reference" and 0.1 < ref["value"] < 10 and ref["source"].startswith("tests/golden/ref/")
 
 
 def test_device_entry_points_capture_into_a_hip_graph():
