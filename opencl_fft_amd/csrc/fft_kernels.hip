@@ -1388,6 +1388,10 @@ int big_split(int logn, BigGeom *g) {
   return 0;
 }
 
+#ifndef CLFA_BIG_XCD
+#define CLFA_BIG_XCD 1   // the column / row block a workgroup of the two-pass kernels takes: XCD-compact (xcd_first) or blockIdx.x
+#endif
+#define CLFA_BIGX ((int)(CLFA_BIG_XCD ? xcd_first(blockIdx.x, gridDim.x) : blockIdx.x))
 template <int LOGN1, bool FWD>
 __global__ __launch_bounds__(256) void k_big_cols(const cpx *__restrict__ data, cpx *__restrict__ scratch,
                                                   const cpx *__restrict__ tabs_g, int logn2, int loglo) {
@@ -1398,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_big_cols(const cpx *__restrict__ data, 
   for (int i = tid; i < N1 / 2; i += 256) s_tab1[i] = tabs_g[i];
   const cpx *tlo = tabs_g + N1 / 2, *thi = tlo + (1 << loglo);
   const int col = tid % C1, tf = tid / C1;
-  const int n2 = blockIdx.x * C1 + col;
+  const int n2 = CLFA_BIGX * C1 + col;
   const long base = ((long)blockIdx.y << (LOGN1 + logn2)) + n2;
   cpx v[16];
 #pragma unroll
@@ -1424,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_big_transpose(const cpx *__restrict__ s
   constexpr int N1 = 1 << LOGN1, TK1 = N1 < 64 ? N1 : 64, TK2 = 4096 / TK1;
   __shared__ cpx tile[TK1 * (TK2 + 1)];
   const int tid = threadIdx.x;
-  const int k2_0 = blockIdx.x * TK2, k1_0 = blockIdx.y * TK1;
+  const int k2_0 = CLFA_BIGX * TK2, k1_0 = blockIdx.y * TK1;
   const long tbase = (long)blockIdx.z << (LOGN1 + logn2);
 #pragma unroll
   for (int r = 0; r < 16; r++) {
@@ -1488,7 +1492,7 @@ __global__ __launch_bounds__(1 << LOGN1) void k_big2_cols(const cpx *__restrict_
   for (int i = tid; i < N1 / 2; i += N1) s_tab1[i] = tabs_g[i];
   const cpx *tlo = tabs_g + N1 / 2, *thi = tlo + (1 << loglo);
   const int col = tid % 16, tf = tid / 16;
-  const int n2 = blockIdx.x * 16 + col;
+  const int n2 = CLFA_BIGX * 16 + col;
   const long base = ((long)blockIdx.y << (LOGN1 + logn2)) + n2;
   cpx v[16];
 #pragma unroll
@@ -1519,7 +1523,7 @@ __global__ __launch_bounds__(512, 4) void k_big2_cols_2x(const cpx *__restrict__
   if (tid < M / 2) s_tabh[tid] = tabs_g[2 * tid];
   const cpx *tlo = tabs_g + M, *thi = tlo + (1 << loglo);
   const int col = tid % 16, tf = tid / 16;
-  const int n2 = blockIdx.x * 16 + col;
+  const int n2 = CLFA_BIGX * 16 + col;
   const long base = ((long)blockIdx.y << (LOGC + 1 + logn2)) + n2;
   cpx va[16], vb[16];
 #pragma unroll
@@ -1575,14 +1579,14 @@ __global__ __launch_bounds__(1 << LOGN2) void k_big2_rows(const cpx *__restrict_
   cpx v[16];
   {
     const int tf = l % T2, row = l / T2;
-    const cpx *p = scratch + tbase + ((long)(blockIdx.x * 16 + row) << LOGN2) + tf;
+    const cpx *p = scratch + tbase + ((long)(CLFA_BIGX * 16 + row) << LOGN2) + tf;
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = p[T2 * e];
   }
   __syncthreads();
   row_passes<LOGN2, 0, FWD>(v, l, s_tab2, s_x);
   const int row2 = l % 16, tf2 = l / 16;
-  cpx *dst = data + tbase + blockIdx.x * 16 + row2;
+  cpx *dst = data + tbase + CLFA_BIGX * 16 + row2;
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     cpx o = v[e];
@@ -1607,7 +1611,7 @@ __global__ __launch_bounds__(512, 4) void k_big2_rows_2x(const cpx *__restrict__
   cpx va[16], vb[16];
   {
     const int tf = l % TC, row = l / TC;
-    const cpx *p = scratch + tbase + ((long)(blockIdx.x * 16 + row) << (LOGC + 1)) + 2 * tf;
+    const cpx *p = scratch + tbase + ((long)(CLFA_BIGX * 16 + row) << (LOGC + 1)) + 2 * tf;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       const f4v q = *reinterpret_cast<const f4v *>(p + 2 * TC * e);
@@ -1620,7 +1624,7 @@ __global__ __launch_bounds__(512, 4) void k_big2_rows_2x(const cpx *__restrict__
   __syncthreads();
   row_passes<LOGC, 0, FWD>(vb, l, s_tabh, s_x);
   const int row2 = l % 16, tf2 = l / 16;
-  cpx *dst = data + tbase + blockIdx.x * 16 + row2;
+  cpx *dst = data + tbase + CLFA_BIGX * 16 + row2;
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const int k = tf2 + TC * e;
