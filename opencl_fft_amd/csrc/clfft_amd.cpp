@@ -266,15 +266,10 @@ struct clfa_fft {
   // n > 65536 (extension): n = N1 x N2; `tabs` then belongs to the N2-point row transform
   BigGeom big{};
   DevBuf bigtabs, scratch2;
-  // n = 16384 on the one-workgroup-per-CU LDS kernel (packed real size 32768 always: the pair maps are fused
-  // there; complex plans when CLFA_LDS14 says so — resolved at creation)
-  bool lds14 = false;
   bool rlds15 = false;   // packed real size 65536: k_rfft_2x<14> (two 16384-point runs per transform, one HBM pass)
   bool c2x13 = false;    // complex n = 16384: k_cfft_2x<13> (two 8192-point runs per transform, two workgroups per CU)
   bool r2x13 = false;    // packed real size 32768: k_rfft_2x<13> (the same, with the pair maps in registers)
-  bool c2x14 = false;    // complex n = 32768 on two 16384-point runs (experiment, CLFA_C2X14=1)
-  bool r2x11 = false;    // packed real size 8192: k_rfft_2x<11, 3> (two 2048-point runs, eight points per lane)
-  DevBuf half2;          // ... their tables: the n = 8192 lane tables + W_16384^t, t < 512
+  DevBuf half2;          // ... the tables of the last two: the n = 8192 lane tables + W_16384^t, t < 512
   long spread_below = 0; // real sizes 32768 / 65536: batches up to this run the four-step pair + pack kernel instead
   // any other length (extension): Bluestein around two power-of-two plans of length blue_m
   int blue_m = 0;
@@ -523,18 +518,16 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     if (const char *mb = getenv("CLFA_BIG_CHUNK_MB")) cap = (size_t)(atoi(mb) > 0 ? atoi(mb) : 256) << 20;   // tuning switch, read once
     if ((e = p->scratch.ensure(per * (cap / per > 0 ? cap / per : 1)))) return e;
   }
-  if (p->logn == kLds14Log) {
-    const char *sw = getenv("CLFA_LDS14");   // tuning switch, read once: complex n = 16384 on the LDS kernel
-    p->lds14 = real || (sw ? atoi(sw) != 0 : kLds14Complex);
-  }
-  p->rlds15 = real && p->logn == 15 && !getenv("CLFA_NO_RLDS15");   // tuning switch, read once
+  p->rlds15 = real && p->logn == 15;
+  p->r2x13 = real && p->logn == 14;
+  p->c2x13 = !real && p->logn == 14;
   // The fused real kernels put one workgroup on a transform (13-23 us for a single one); a few transforms are
   // faster spread over the column / row blocks of the four-step pair plus the pack kernel (11 us): real plans of
   // these two sizes carry both sets of tables and exec picks by batch (p->spread_below).
-  const bool lane14 = p->lds14 || p->rlds15;
-  const bool both = lane14 && real;
+  const bool lane14 = p->rlds15;     // k_rfft_2x<14> runs on the 16384-point lane tables
+  const bool both = p->rlds15 || p->r2x13;
   const int fourlog = rowlog;
-  if (lane14) rowlog = kLds14Log;   // the lane tables are the 16384-point ones
+  if (lane14) rowlog = kLds14Log;
   if (both) p->spread_below = p->di.num_cus / 8;   // measured crossover: between 32 and 64 transforms
   if (rowlog <= kLdsMaxLog || lane14) {
     if (kLdsTwoLevel(rowlog)) {
@@ -577,37 +570,6 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     fill_w2(h, n, fwd ? -1.f : 1.f);
     if ((e = upload(p->w2, h.data(), sizeof(cpx) * n))) return e;
     p->tabs.w2 = (const cpx *)p->w2.p;
-  }
-  if (!real && p->logn == 14 && !p->lds14) {
-    const char *sw = getenv("CLFA_C2X13");   // tuning switch, read once: 0 = complex n = 16384 on the four-step kernel
-    p->c2x13 = sw ? atoi(sw) != 0 : true;
-  }
-  if (real && p->logn == 14) {
-    const char *sw = getenv("CLFA_R2X13");   // tuning switch, read once: 0 = packed real size 32768 on k_fft_lds<14>
-    p->r2x13 = sw ? atoi(sw) != 0 : true;
-  }
-  if (!real && p->logn == 15 && getenv("CLFA_C2X14") && atoi(getenv("CLFA_C2X14"))) {   // tuning switch, read once
-    p->c2x14 = true;
-    h.clear();
-    auto w = [&](long k, long nn) { h.push_back(mk((float)cos(k * 2 * kPI / nn), -(float)sin(k * 2 * kPI / nn))); };
-    for (int j = 0; j < 16; j++)
-      for (int t = 0; t < 16; t++) w(j * t, 256);
-    for (int k = 0; k < 4; k++)
-      for (int j = 0; j < 256; j++) w(((1 << k) * j) & 4095, 4096);
-    for (int m = 1; m <= 3; m++)
-      for (int t = 0; t < 1024; t++) w(m * t, 16384);
-    for (int t = 0; t < 1024; t++) w(t, 32768);
-    if ((e = upload(p->half2, h.data(), sizeof(cpx) * h.size()))) return e;
-  }
-  if (real && p->logn == 12) {
-    // tuning switch, read once: 1 = packed real size 8192 on two 2048-point runs (measured 4 % slower than k_fft_lds<12>
-    // with its pair exchange through LDS: 4.70 against 4.91 TB/s, so not the default)
-    const char *sw = getenv("CLFA_R2X11");
-    p->r2x11 = sw ? atoi(sw) != 0 : false;
-    if (p->r2x11) {
-      fill_twiddle(h, 1024, 2048, 1, -1.f);   // the half table of the 2048-point runs
-      if ((e = upload(p->half2, h.data(), sizeof(cpx) * 1024))) return e;
-    }
   }
   if (p->c2x13 || p->r2x13) {
     // the n = 8192 lane tables (as above) + the radix-2 step's lane constants W_16384^t
@@ -690,9 +652,9 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
   if (p->logn > kMaxLog) return "k_big_cols";
   if (p->blue_m) return "bluestein";
-  if (p->rlds15 || p->r2x13 || p->r2x11) return "k_rfft_2x";
-  if (p->c2x13 || p->c2x14) return "k_cfft_2x";
-  return (p->logn <= kLdsMaxLog || p->lds14) ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
+  if (p->rlds15 || p->r2x13) return "k_rfft_2x";
+  if (p->c2x13) return "k_cfft_2x";
+  return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
 }
 
 int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
@@ -729,22 +691,10 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
     HIP_TRY(launch_rfft_lds15(p->fwd, d, p->tabs, batch, p->di, s));
     return CLFA_SUCCESS;
   }
-  if (p->r2x11) {
-    FftTables t2 = p->tabs;
-    t2.half = (const cpx *)p->half2.p;
-    HIP_TRY(launch_rfft_2x11(p->fwd, d, t2, batch, p->di, s));
-    return CLFA_SUCCESS;
-  }
   if (p->r2x13 && !spread) {
     FftTables t2 = p->tabs;
     t2.half = (const cpx *)p->half2.p;
     HIP_TRY(launch_rfft_2x13(p->fwd, d, t2, batch, p->di, s));
-    return CLFA_SUCCESS;
-  }
-  if (p->c2x14 && batch * 4 > p->di.num_cus) {
-    FftTables t2 = p->tabs;
-    t2.half = (const cpx *)p->half2.p;
-    HIP_TRY(launch_cfft_2x14(p->fwd, scale, d, t2, batch, p->di, s));
     return CLFA_SUCCESS;
   }
   if (p->c2x13 && batch * 4 > p->di.num_cus) {   // (fewer transforms: spread over the four-step column / row kernels)
@@ -753,7 +703,7 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
     HIP_TRY(launch_cfft_2x13(p->fwd, scale, d, t2, batch, p->di, s));
     return CLFA_SUCCESS;
   }
-  if (p->logn <= kLdsMaxLog || (p->lds14 && !spread)) {
+  if (p->logn <= kLdsMaxLog) {
     int mode = !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R);
     HIP_TRY(launch_fft_lds(p->logn, p->fwd, mode, scale, d, p->tabs, batch, p->di, s));
     return CLFA_SUCCESS;

@@ -607,29 +607,6 @@ hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch
   else hipLaunchKernelGGL((k_rfft_2x<14, false, false>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
   return hipGetLastError();
 }
-// real size 8192: t.half = the half table of 2048 points (1024 entries), t.w2 = the plan's r2c table (4096 entries)
-hipError_t launch_rfft_2x11(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
-  if (batch <= 0) return hipSuccess;
-  // persistent 256-lane workgroups, 25 KiB of LDS each: as many as are resident at once (a grid beyond that would run
-  // its last workgroups after the others have finished their whole share)
-  static int per_cu[2] = {0, 0};
-  int &nb = per_cu[fwd ? 1 : 0];
-  if (nb == 0) {
-    int q = 0;
-    const hipError_t e = fwd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_rfft_2x<11, true, true, 3>, 256, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_rfft_2x<11, false, false, 3>, 256, 0);
-    if (e != hipSuccess || q < 1) {
-      (void)hipGetLastError();
-      q = 4;
-    }
-    nb = q;
-  }
-  const long cap = (long)nb * di.num_cus;
-  const int grid = (int)(batch < cap ? batch : cap);
-  if (fwd) hipLaunchKernelGGL((k_rfft_2x<11, true, true, 3>), dim3(grid), dim3(256), 0, s, data, t.half, t.w2, batch);
-  else hipLaunchKernelGGL((k_rfft_2x<11, false, false, 3>), dim3(grid), dim3(256), 0, s, data, t.half, t.w2, batch);
-  return hipGetLastError();
-}
 // real size 32768: t.half = the n = 8192 lane tables (kLane13Size), t.w2 = the plan's r2c table (16384 entries)
 hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
   if (batch <= 0) return hipSuccess;
@@ -729,10 +706,6 @@ static hipError_t launch_cfft_2x_n(bool fwd, bool scale, cpx *data, const FftTab
 hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
                             hipStream_t s) {
   return launch_cfft_2x_n<13>(fwd, scale, data, t, batch, di, s);
-}
-hipError_t launch_cfft_2x14(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
-                            hipStream_t s) {
-  return launch_cfft_2x_n<14>(fwd, scale, data, t, batch, di, s);
 }
 
 // ---------------------------------------------------------------------------------
@@ -915,7 +888,7 @@ hipError_t launch_fft_lds(int logn, bool fwd, int mode, bool scale, cpx *data, c
   case L:         \
     return launch_lds_n<L>(fwd, mode, scale, data, t, batch, di, s);
     CLFA_N(1) CLFA_N(2) CLFA_N(3) CLFA_N(4) CLFA_N(5) CLFA_N(6) CLFA_N(7) CLFA_N(8) CLFA_N(9) CLFA_N(10)
-    CLFA_N(11) CLFA_N(12) CLFA_N(13) CLFA_N(14)
+    CLFA_N(11) CLFA_N(12) CLFA_N(13)
 #undef CLFA_N
     default:
       return hipErrorInvalidValue;
@@ -1383,8 +1356,7 @@ int big_split(int logn, BigGeom *g) {
     g->logn1 = logn - g->logn2;
   }
   g->loglo = 12;
-  const char *sw = getenv("CLFA_BIG2X");   // tuning switch, read once (at plan creation): 0 = one-run 1024-point blocks
-  g->two_run = sw ? atoi(sw) != 0 : true;
+  g->two_run = true;   // (the one-run form of the 1024-point blocks lost its A/B by 1.4-6 % and left the library in round 4)
   return 0;
 }
 
@@ -1663,31 +1635,26 @@ static hipError_t launch_fft_big2(const BigGeom &g, bool fwd, bool scale, cpx *d
   switch (g.logn1) {
     case 8: e = launch_big2_cols<8>(g, fwd, data, scratch, bigtabs, batch, s); break;
     case 9: e = launch_big2_cols<9>(g, fwd, data, scratch, bigtabs, batch, s); break;
-    case 10:
-      if (g.two_run) {
-        const dim3 grid((1 << g.logn2) / 16, (unsigned)batch);
-        if (fwd) hipLaunchKernelGGL((k_big2_cols_2x<true>), grid, dim3(512), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
-        else hipLaunchKernelGGL((k_big2_cols_2x<false>), grid, dim3(512), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
-        e = hipGetLastError();
-      } else {
-        e = launch_big2_cols<10>(g, fwd, data, scratch, bigtabs, batch, s);
-      }
+    case 10: {   // 1024-point columns as two 512-point runs (two workgroups per CU)
+      const dim3 grid((1 << g.logn2) / 16, (unsigned)batch);
+      if (fwd) hipLaunchKernelGGL((k_big2_cols_2x<true>), grid, dim3(512), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+      else hipLaunchKernelGGL((k_big2_cols_2x<false>), grid, dim3(512), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+      e = hipGetLastError();
       break;
+    }
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
   switch (g.logn2) {
     case 9: return launch_big2_rows<9>(g, fwd, scale, scratch, data, sub.half, batch, s);
-    case 10:
-      if (g.two_run) {
-        const dim3 grid((1 << g.logn1) / 16, (unsigned)batch);
-        const float inv_n = 1.0f / (float)(1L << g.logn);
-        if (fwd && scale) hipLaunchKernelGGL((k_big2_rows_2x<true, true>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
-        else if (fwd) hipLaunchKernelGGL((k_big2_rows_2x<true, false>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
-        else hipLaunchKernelGGL((k_big2_rows_2x<false, false>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
-        return hipGetLastError();
-      }
-      return launch_big2_rows<10>(g, fwd, scale, scratch, data, sub.half, batch, s);
+    case 10: {   // ... and the 1024-point rows
+      const dim3 grid((1 << g.logn1) / 16, (unsigned)batch);
+      const float inv_n = 1.0f / (float)(1L << g.logn);
+      if (fwd && scale) hipLaunchKernelGGL((k_big2_rows_2x<true, true>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
+      else if (fwd) hipLaunchKernelGGL((k_big2_rows_2x<true, false>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
+      else hipLaunchKernelGGL((k_big2_rows_2x<false, false>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
+      return hipGetLastError();
+    }
     default: return hipErrorInvalidValue;
   }
 }

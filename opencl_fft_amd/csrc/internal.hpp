@@ -16,11 +16,9 @@ constexpr int kLdsMaxLog = 13;
 // kLane13Lds entries live in LDS
 constexpr bool kLdsTwoLevel(int logn) { return logn >= 13; }
 constexpr int kLane13Lds = 1280, kLane13Size = 1792;
-// n = 16384 (the one-workgroup-per-CU LDS kernel: 1024 lanes, passes 16 x 16 x 16 x 4; it serves the packed real
-// transforms of size 32768 with the pair maps fused, fft_device.hpp LaneTab14): the same LDS part, then
-// [W_16384^t | W_16384^(2 t) | W_16384^(3 t)], t < 1024
+// the 16384-point chains of k_rfft_2x<14> (packed real size 65536: 1024 lanes, passes 16 x 16 x 16 x 4, fft_device.hpp
+// LaneTab14): the same LDS part, then [W_16384^t | W_16384^(2 t) | W_16384^(3 t)], t < 1024
 constexpr int kLds14Log = 14, kLane14Size = kLane13Lds + 3 * 1024;
-constexpr bool kLds14Complex = false;   // complex n = 16384: the four-step kernel unless CLFA_LDS14=1 (measured: DESIGN.md)
 constexpr int kMaxLog = 16;  // reference int32 index bound, cl_fft.cpp:32
 
 struct FftTables {      // all device pointers, owned by the plan
@@ -46,15 +44,9 @@ hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch
 // packed real size 32768 the same way on two 8192-point runs (two 512-lane workgroups per CU); t.half = the n = 8192
 // lane tables (kLane13Size), t.w2 = the plan's r2c table
 hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
-// packed real size 8192 on two 2048-point runs, eight points per lane; t.half = the half table of 2048 points
-hipError_t launch_rfft_2x11(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
 // complex n = 16384 as two 8192-point runs + a radix-2 step in registers; t.half = the n = 8192 lane tables
 // (kLane13Size) followed by W_16384^t, t < 512
 hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
-                            hipStream_t s);
-// ... and n = 32768 as two 16384-point runs (t.half = the n = 16384 lane tables, kLane14Size, followed by W_32768^t,
-// t < 1024): experiment behind CLFA_C2X14=1
-hipError_t launch_cfft_2x14(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
                             hipStream_t s);
 
 // four-step FFT, n = 2^logn in (2^kLdsMaxLog, 2^kMaxLog]; scratch = fourstep_grid() * n complex

@@ -153,24 +153,13 @@ def test_cfft_resident_kernel_both_directions():
 def test_cfft_batched_kernels_vs_reference_vectors(n):
     """The reference's own outputs (Clcfft::transform, cl_fft.cpp:153-161, run on the MI355X through OpenCL) against the
     BATCHED kernels: a single transform of these lengths goes to the column / row kernel pair, so the golden input
-    LCG(12345) is replicated 70 times — the batch that selects k_fft_res16 (n = 65536) resp. the persistent four-step
-    kernel — and EVERY transform of the batch is compared with the reference's vector."""
+    LCG(12345) is replicated 70 times — the batch that selects k_fft_res16 (n = 65536), the persistent four-step kernel
+    (n = 32768) and k_cfft_2x (n = 16384) — and EVERY transform of the batch is compared with the reference's vector."""
     batch = 70
     x = np.tile(util.lcg_complex(12345, n), (batch, 1))
-    want = {65536: "k_fft_res16", 32768: "k_fft_4step", 16384: "k_cfft_2x"}[n]
-    cases = [(True, want), (False, want)]
-    if n == 16384:   # ... and the four-step kernel of that length, still in the library behind its plan-time switch
-        cases += [(True, "k_fft_4step"), (False, "k_fft_4step")]
-    if n == 32768:   # ... and that length on two 16384-point runs (measured equal to the four-step kernel; not the default)
-        cases += [(True, "k_cfft_2x"), (False, "k_cfft_2x")]
-    for fwd, kernel in cases:
-        if kernel != want:
-            os.environ["CLFA_C2X13" if n == 16384 else "CLFA_C2X14"] = "0" if n == 16384 else "1"
-        try:
-            plan = fa.Clcfft(0, n, fwd)
-        finally:
-            os.environ.pop("CLFA_C2X13", None)
-            os.environ.pop("CLFA_C2X14", None)
+    kernel = {65536: "k_fft_res16", 32768: "k_fft_4step", 16384: "k_cfft_2x"}[n]
+    for fwd in (True, False):
+        plan = fa.Clcfft(0, n, fwd)
         assert plan.kernel_name() == kernel
         y = x.copy()
         assert plan.transform(y) == 0
@@ -231,24 +220,14 @@ def test_rfft_out_of_place(size, batch):
     assert_parity(dst.cpu().numpy().view(np.complex64), oracle.rfft_forward(r), what="rfft oop size %d" % size)
 
 
-@pytest.mark.parametrize("size,kernel", [(8192, "k_rfft_2x"), (8192, "k_fft_lds"), (32768, "k_rfft_2x"), (32768, "k_fft_lds"),
-                                         (65536, "k_rfft_2x"), (131072, None)])
+@pytest.mark.parametrize("size,kernel", [(8192, "k_fft_lds"), (32768, "k_rfft_2x"), (65536, "k_rfft_2x"), (131072, None)])
 def test_rfft_batched_kernels_vs_reference_vectors(size, kernel):
     """Clrfft::transform (cl_fft.cpp:267-296) vectors against the one-pass real kernels: more than 32 transforms select
-    k_rfft_2x (two 2048- / 8192- / 16384-point runs for sizes 8192 / 32768 / 65536; sizes 8192 and 32768 also on
-    k_fft_lds<12> / <14>, still in the library behind their plan-time switches) instead of the spread path a single transform takes; every
+    k_rfft_2x (two 8192- / 16384-point runs for sizes 32768 / 65536) instead of the spread path a single transform takes; every
     transform of the batch against the reference's forward, round-trip and arbitrary-spectrum inverse vectors, bin M/2
     (the reference's never-conjugated self-paired bin, cl_fft.cpp:278) included."""
     batch, m = 70, size // 2
-    if size == 8192 and kernel == "k_rfft_2x":
-        os.environ["CLFA_R2X11"] = "1"   # (two 2048-point runs: measured slower than k_fft_lds<12>, not the default)
-    if size == 32768 and kernel == "k_fft_lds":
-        os.environ["CLFA_R2X13"] = "0"
-    try:
-        f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
-    finally:
-        os.environ.pop("CLFA_R2X13", None)
-        os.environ.pop("CLFA_R2X11", None)
+    f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
     if kernel is not None:
         assert f.kernel_name() == kernel and i.kernel_name() == kernel
     x = np.tile(util.lcg_sym(12345, size), (batch, 1))
@@ -417,20 +396,12 @@ def test_config3_full_size_roundtrip():
 # own to compare with: the yardstick is numpy's float64 FFT under the reference's conventions
 # (forward scaled by 1/n, inverse unscaled), same norm-relative 1e-6 criterion.
 
-@pytest.mark.parametrize("logn,batch,one_run", [(17, 3, False), (18, 2, False), (19, 1, False), (20, 2, False), (19, 2, True),
-                                                (20, 1, True), (21, 1, False), (22, 1, False), (24, 1, False)])
-def test_cfft_big_sizes(logn, batch, one_run):
-    """(one_run: the 1024-point column / row blocks of 2^19 and 2^20 in their one-workgroup-per-CU form, behind its
-    plan-time switch; the default is two 512-point runs per column / row, two workgroups per CU)"""
+@pytest.mark.parametrize("logn,batch", [(17, 3), (18, 2), (19, 1), (19, 2), (20, 2), (20, 1), (21, 1), (22, 1), (24, 1)])
+def test_cfft_big_sizes(logn, batch):
     n = 1 << logn
     rng = np.random.default_rng(logn)
     x = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
-    if one_run:
-        os.environ["CLFA_BIG2X"] = "0"
-    try:
-        f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
-    finally:
-        os.environ.pop("CLFA_BIG2X", None)
+    f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
     assert f.get_error() == 0 and i.get_error() == 0
     assert f.workspace_bytes() >= 8 * n
     y = x.copy()
