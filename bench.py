@@ -376,7 +376,7 @@ def main():
     # 3b. the same workload OUT OF PLACE (extension clfa_fft_exec_dev_oop; the reference's device side is out of place
     # too, data1 -> data2, cl_fft.cpp:138-151): forward A -> B, inverse B -> A, same machinery.  Never the headline.
     oop = None
-    if a.workload == "c2c" and world == 1 and not a.series_out and not os.environ.get("CLFA_BENCH_NO_OOP"):
+    if a.workload == "c2c" and world == 1 and not a.series_out and not a.no_other_workloads:   # (not in profiling runs: same kernel symbol)
         other = torch.empty_like(wl.data)
         bufs = (wl.data, other)
         in_place_step = wl.step
