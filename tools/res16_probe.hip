@@ -173,6 +173,27 @@ int main() {
   for (int i = 0; i < 1792; i++) t[i] = mk((float)cos(i * 0.001), (float)sin(i * 0.001));   // unit-modulus stand-ins: timing only
   CK(hipMemcpy(tabs, t.data(), 1792 * 8, hipMemcpyHostToDevice));
   printf("k_fft_res16 probe: %ld transforms, %d workgroups\n", batch, cus);
+  if (getenv("PROBE_GRID")) {   // fewer workgroups than CUs: does the chip need all 256 to move these bytes?
+    for (int round = 0; round < 3; round++)
+      for (int g : {256, 248, 240, 224, 208, 192, 160, 128}) {
+        const long b2 = (batch / g) * g;   // whole rounds only
+        char nm[64];
+        snprintf(nm, sizeof nm, "grid %3d, %4ld transforms", g, b2);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        auto launch = [&] { hipLaunchKernelGGL((k_fft_res16<true, false, 0>), dim3(g), dim3(256), 0, 0, data, data, slots, tabs, b2, (unsigned long long *)nullptr); };
+        for (int i = 0; i < 6; i++) launch();
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 30; i++) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-30s %8.3f ms  %6.2f TB/s alg\n", nm, ms / 30, b2 * 65536.0 * 16 / (ms / 30) * 1e-9);
+      }
+    return 0;
+  }
   if (getenv("PROBE_MAP")) {   // transform -> workgroup assignments, in place
     for (int round = 0; round < 3; round++)
       for (unsigned long long mode = 0; mode < 4; mode++) {
