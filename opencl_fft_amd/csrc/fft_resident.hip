@@ -132,7 +132,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const cpx *base) {
 //   column block (blockIdx rotates the 128-byte column offset; results are then garbage)
 enum { kProbeNoLoad = 1, kProbeNoStore = 2, kProbeNoBarrier = 4, kProbeNoSlot = 8, kProbeStamps = 16,
        kProbeNoWait = 32, kProbeNoMath = 64, kProbePhase1Only = 128, kProbeRotate = 256, kProbeGridSync = 512,
-       kProbeSlots = 1024 };
+       kProbeSlots = 1024, kProbePack = 2048 };
+//   2048 a third phase: the workgroup re-reads its own transform (pairs i, n - i, 8-byte accesses) and writes it back —
+//   the memory behaviour of a pair map fused behind phase 2 (what would real size 131072 cost in one launch?)
 //   1024 time slots: every workgroup starts phase k no earlier than its own start + S[k] (slot lengths in 10 ns
 //   ticks at dbg[2048], dbg[2049]): read and write phases aligned chip-wide without any communication
 //   512 a grid-wide barrier at every phase boundary (counter at dbg[1024]; the stamps exclude the wait):
@@ -754,6 +756,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       if constexpr (!(PROBE & kProbeNoLoad)) res_load_land(xn + ((1 + rot) & 15) * 16, L.voff);
     }
 #ifdef CLFA_RES16_PROBE
+    if constexpr (PROBE & kProbePack) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const __amdgpu_buffer_rsrc_t ry = res_rsrc(y);
+      int lt = tid;
+      asm volatile("" : "+v"(lt));
+#pragma unroll 1
+      for (int k = 0; k < 128; k += 8) {
+        u32x2 a[8], bq[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = lt + 256 * (k + u);
+          a[u] = __builtin_amdgcn_raw_buffer_load_b64(ry, i * 8, 0, 2);
+          bq[u] = __builtin_amdgcn_raw_buffer_load_b64(ry, (kN - 1 - i) * 8, 0, 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = lt + 256 * (k + u);
+          const cpx ci = __builtin_bit_cast(cpx, a[u]), cj = __builtin_bit_cast(cpx, bq[u]);
+          cpx oi, oj;
+          r2c_pair(ci, cj, s_tab[(i >> 7) & 255], oi, oj);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oi), ry, i * 8, 0, 2);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oj), ry, (kN - 1 - i) * 8, 0, 2);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if constexpr (PROBE & kProbeStamps) clk2 += __builtin_amdgcn_s_memtime() - t0;
     if constexpr (PROBE & kProbeGridSync) res_probe_grid_sync(dbg, epoch);
     if constexpr (PROBE & kProbeSlots) {

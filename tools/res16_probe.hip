@@ -173,6 +173,13 @@ int main() {
   for (int i = 0; i < 1792; i++) t[i] = mk((float)cos(i * 0.001), (float)sin(i * 0.001));   // unit-modulus stand-ins: timing only
   CK(hipMemcpy(tabs, t.data(), 1792 * 8, hipMemcpyHostToDevice));
   printf("k_fft_res16 probe: %ld transforms, %d workgroups\n", batch, cus);
+  if (getenv("PROBE_PACK")) {   // a pair-map phase behind phase 2, inside the launch
+    for (int round = 0; round < 3; round++) {
+      run<16>("full + stamps", data, slots, tabs, dbg, batch, cus);
+      run<2048 | 16>("full + in-launch pair pass + stamps", data, slots, tabs, dbg, batch, cus);
+    }
+    return 0;
+  }
   if (getenv("PROBE_GRID")) {   // fewer workgroups than CUs: does the chip need all 256 to move these bytes?
     for (int round = 0; round < 3; round++)
       for (int g : {256, 248, 240, 224, 208, 192, 160, 128}) {
