@@ -509,7 +509,30 @@ template <int LOGN, int LOGE> static void both() {
   if (!(a < 5e-7) || !(b < 5e-7)) g_fail = 1;
 }
 
+// xcd_first(): for every grid the persistent kernels launch, the workgroups' first transforms are a permutation of
+// 0 .. grid - 1 (then every workgroup steps by the grid size: each transform is taken exactly once), workgroups i and
+// i + 8 (one XCD under round-robin dispatch) take ADJACENT transforms, and grids that are not multiples of 8 fall back to
+// "workgroup i takes i"
+static int assignment() {
+  int bad = 0;
+  for (unsigned grid : {1u, 2u, 7u, 8u, 16u, 70u, 72u, 128u, 248u, 256u, 304u, 512u, 1024u}) {
+    std::vector<int> seen(grid, 0);
+    for (unsigned i = 0; i < grid; i++) {
+      const long f = clfa::xcd_first(i, grid);
+      if (f < 0 || f >= (long)grid) { bad++; continue; }
+      seen[f]++;
+      if (grid % 8 == 0) {
+        if (i + 8 < grid && clfa::xcd_first(i + 8, grid) != f + 1) bad++;
+      } else if (f != (long)i) bad++;
+    }
+    for (unsigned i = 0; i < grid; i++) bad += seen[i] != 1;
+  }
+  printf("xcd_first: %s\n", bad ? "FAIL" : "a permutation for every grid, XCD-compact for multiples of 8");
+  return bad != 0;
+}
+
 int main() {
+  g_fail |= assignment();
   both<1, 1>(); both<2, 2>(); both<3, 3>(); both<4, 4>(); both<5, 4>(); both<6, 4>(); both<7, 4>();
   both<8, 4>(); both<9, 4>(); both<10, 4>(); both<11, 4>(); both<12, 4>(); both<13, 4>(); both<14, 4>();
   both<6, 2>(); both<6, 3>(); both<10, 3>(); both<9, 2>(); both<7, 3>(); both<8, 3>();
