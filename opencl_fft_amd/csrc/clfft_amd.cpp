@@ -654,7 +654,7 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (p->blue_m) return "bluestein";
   if (p->rlds15 || p->r2x13) return "k_rfft_2x";
   if (p->c2x13) return "k_cfft_2x";
-  return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, 0) : name_fft_4step(p->logn);
+  return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R)) : name_fft_4step(p->logn);
 }
 
 int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {

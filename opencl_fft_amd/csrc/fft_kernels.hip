@@ -895,7 +895,10 @@ hipError_t launch_fft_lds(int logn, bool fwd, int mode, bool scale, cpx *data, c
   }
 }
 
-const char *name_fft_lds(int, bool, int) { return "k_fft_lds"; }
+const char *name_fft_lds(int logn, bool, int mode) {
+  if (logn >= 2 && (logn <= 6 || (mode != MODE_C2C && logn <= 8))) return "k_fft_small";
+  return "k_fft_lds";
+}
 
 // ---------------------------------------------------------------------------------
 // four-step FFT for n = 2^14 .. 2^16
