@@ -87,6 +87,34 @@ def traffic_from_profiles(key):
         return None, None
 
 
+def reference_timing():
+    """The UNMODIFIED reference (Clcfft::transform, cl_fft.cpp:153-161: one N = 65536 transform per call, 17 launches and two
+    PCIe copies each) timed on this machine's OpenCL device by oracle/_ref/ref_driver (built from the reference's sources in
+    place by `make -C oracle ref`; the binary travels with the repository, the sources do not) — live when the binary and
+    an OpenCL device are there, else the measurement committed with the golden vectors.  The reference has no CPU path of
+    its own: its "CPU path" would be these same kernels on a CPU OpenCL device, and no CPU ICD exists on these machines."""
+    import numpy as np
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    what = "Clcfft::transform N=65536, one transform per call, PCIe copies included"
+    if os.path.exists(exe):
+        try:
+            out = subprocess.run([exe, "/tmp", str(int(os.environ.get("LOCAL_RANK", "0"))), "time"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, timeout=120)
+            f = out.stdout.decode().split()
+            if out.returncode == 0 and len(f) >= 3:
+                return {"value": float(f[1]), "unit": "Gsamples/s", "us_per_transform": float(f[0]), "kind": "reference",
+                        "what": what, "source": "measured in this run: oracle/_ref/ref_driver time (%d transforms, OpenCL device %s)"
+                        % (int(f[2]), " ".join(f[3:]) or "?")}
+        except (OSError, subprocess.SubprocessError, ValueError):
+            pass
+    try:
+        t_ref = np.fromfile(os.path.join(ROOT, "tests", "golden", "ref", "timing_ref_cfft65536.bin"), dtype=np.float64)
+        return {"value": float(t_ref[1]), "unit": "Gsamples/s", "us_per_transform": float(t_ref[0]), "kind": "reference",
+                "what": what, "source": "tests/golden/ref/timing_ref_cfft65536.bin (committed measurement of the same binary on an MI355X of this pool)"}
+    except OSError:
+        return None
+
+
 def cpu_baseline_c2c(n, sample):
     """oracle (CPU restatement of the reference's reorder + log2N radix-2 passes) on all host
     cores over `sample` transforms of the same workload"""
@@ -480,15 +508,7 @@ def main():
         if oop is not None:
             rec["config"]["out_of_place"] = oop
         if a.workload == "c2c":
-            # the unmodified reference (Clcfft::transform, cl_fft.cpp:153-161) run on an MI355X of this pool through OpenCL by
-            # oracle/ref_driver.cpp: one transform per call, 17 launches and two PCIe copies each (a committed measurement)
-            try:
-                t_ref = np.fromfile(os.path.join(ROOT, "tests", "golden", "ref", "timing_ref_cfft65536.bin"), dtype=np.float64)
-                rec["reference_opencl_same_gpu"] = {"value": float(t_ref[1]), "unit": "Gsamples/s", "us_per_transform": float(t_ref[0]),
-                                                    "kind": "reference", "what": "Clcfft::transform N=65536, one transform per call, "
-                                                    "PCIe copies included", "source": "tests/golden/ref/timing_ref_cfft65536.bin"}
-            except OSError:
-                pass
+            rec["reference_opencl_same_gpu"] = reference_timing()
         if cold is not None:
             # the contract's W + K launches read cold (before the self-check): inside the chip's start-up clock ramp
             rec["ms_per_step_cold"] = cold["ms_per_step"]

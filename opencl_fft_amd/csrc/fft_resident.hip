@@ -132,7 +132,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const cpx *base) {
 //   column block (blockIdx rotates the 128-byte column offset; results are then garbage)
 enum { kProbeNoLoad = 1, kProbeNoStore = 2, kProbeNoBarrier = 4, kProbeNoSlot = 8, kProbeStamps = 16,
        kProbeNoWait = 32, kProbeNoMath = 64, kProbePhase1Only = 128, kProbeRotate = 256, kProbeGridSync = 512,
-       kProbeSlots = 1024, kProbePack = 2048 };
+       kProbeSlots = 1024, kProbePack = 2048, kProbeNoXchg = 4096 };
+//   4096 no LDS exchange at all (no ds_write / ds_read / barriers between the two passes of a block: garbage results) —
+//   the upper bound of what hiding the exchange behind arithmetic could buy
 //   2048 a third phase: the workgroup re-reads its own transform (pairs i, n - i, 8-byte accesses) and writes it back —
 //   the memory behaviour of a pair map fused behind phase 2 (what would real size 131072 cost in one launch?)
 //   1024 time slots: every workgroup starts phase k no earlier than its own start + S[k] (slot lengths in 10 ns
@@ -388,6 +390,7 @@ template <bool FWD, int PROBE = 0, class H = HookNone>
 __device__ __forceinline__ void res_col_block(cpx (&v)[16], const ResLane &L, int cb, const cpx *s_tab, cpx *s_x,
                                               const H &hook = H()) {
   if constexpr (!(PROBE & kProbeNoMath)) CLFA_DFT16_H(FWD, v, hook, kMapColA);
+  if constexpr (!(PROBE & kProbeNoXchg)) {
   res_barrier<PROBE>();   // the previous block's readers are done with the exchange buffer
   {
     f4 *pw = reinterpret_cast<f4 *>(L.xa_w);
@@ -397,6 +400,7 @@ __device__ __forceinline__ void res_col_block(cpx (&v)[16], const ResLane &L, in
   res_barrier<PROBE>();
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = L.xa_r[16 * e];
+  }
   if constexpr (PROBE & kProbeNoMath) return;
   // second pass: inputs times W_256^(t j) (row t of the table), then the butterflies
   {
@@ -501,6 +505,7 @@ template <int RB> __device__ __forceinline__ void res_fetch_static(cpx (&v)[16],
 template <bool FWD, int PROBE = 0, class H = HookNone>
 __device__ __forceinline__ void res_row_block(cpx (&v)[16], const ResLane &L, const H &hook = H()) {
   if constexpr (!(PROBE & kProbeNoMath)) CLFA_DFT16_H(FWD, v, hook, kMapRowC);
+  if constexpr (!(PROBE & kProbeNoXchg)) {
   res_barrier<PROBE>();
   {
     f4 *pw = reinterpret_cast<f4 *>(L.xb_w);
@@ -510,6 +515,7 @@ __device__ __forceinline__ void res_row_block(cpx (&v)[16], const ResLane &L, co
   res_barrier<PROBE>();
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = L.xb_r[18 * e];
+  }
   if constexpr (PROBE & kProbeNoMath) return;
   {
     const f4 *pt = reinterpret_cast<const f4 *>(L.tw_row);

@@ -142,7 +142,7 @@ static void run_g11(cl_device_id dev) {
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: ref_driver <outdir> [device-index] [g11]\n");
+    fprintf(stderr, "usage: ref_driver <outdir> [device-index] [g11 | time]\n");
     return 2;
   }
   g_dir = argv[1];
@@ -159,6 +159,33 @@ int main(int argc, char **argv) {
   fprintf(stderr, "ref_driver: %u device(s), using %d: %s\n", num, devidx, name);
   cl_device_id dev = ids[devidx];
 
+  if (argc > 3 && !strcmp(argv[3], "time")) {
+    // only the timing of the reference's own path (bench.py runs this live where an OpenCL device exists): one line on stdout,
+    // "<us per transform> <Gsamples/s> <transforms timed> <device name>"; nothing is written to <outdir>
+    const int N = 65536;
+    cl_fft::Clcfft f(dev, N, true);
+    if (f.get_error() != CL_SUCCESS) {
+      fprintf(stderr, "Clcfft setup: %s\n", cl_fft::cl_error_string(f.get_error()));
+      return 4;
+    }
+    std::vector<cf> x(N);
+    unsigned sd = 12345;
+    for (auto &c : x) {
+      sd = sd * 1664525u + 1013904223u;
+      const float re = (sd >> 8) / 8388608.f - 1.f;
+      sd = sd * 1664525u + 1013904223u;
+      c = cf(re, (sd >> 8) / 8388608.f - 1.f);
+    }
+    cl_fft::Clcfft g(dev, N, false);
+    for (int k = 0; k < 4; k++) (k & 1 ? g : f).transform(x.data());   // warm-up; forward / inverse keep the data O(1)
+    const int reps = 200;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; k++) (k & 1 ? g : f).transform(x.data());
+    auto t1 = std::chrono::steady_clock::now();
+    const double us = std::chrono::duration<double, std::micro>(t1 - t0).count() / reps;
+    printf("%.3f %.6f %d %s\n", us, N / us * 1e-3, reps, name);
+    return 0;
+  }
   const bool only11 = argc > 3 && !strcmp(argv[3], "g11");   // only the G11 vectors (manifest_g11.json)
   g_manifest = fopen((g_dir + (only11 ? "/manifest_g11.json" : "/manifest.json")).c_str(), "w");
   fprintf(g_manifest, "{\n  \"_device\": \"%s\"", name);

@@ -161,7 +161,8 @@ def test_bench_default_line_carries_every_single_gpu_config():
     assert oop["steps"] % 2 == 0 and 0 < oop["roofline"]["frac"] < 1 and oop["roofline"]["kernel"] == "k_fft_res16"
     assert "in place" in r["config"]["workload"] and r["config"]["library"].endswith("libclfft_amd.so")
     ref = r["reference_opencl_same_gpu"]
-    assert ref["kind"] == "reference" and 0.1 < ref["value"] < 10 and ref["source"].startswith("tests/golden/ref/")
+    assert ref["kind"] == "reference" and 0.1 < ref["value"] < 10
+    assert ref["source"].startswith(("tests/golden/ref/", "measured in this run"))
 
 
 def test_device_entry_points_capture_into_a_hip_graph():

@@ -173,6 +173,16 @@ int main() {
   for (int i = 0; i < 1792; i++) t[i] = mk((float)cos(i * 0.001), (float)sin(i * 0.001));   // unit-modulus stand-ins: timing only
   CK(hipMemcpy(tabs, t.data(), 1792 * 8, hipMemcpyHostToDevice));
   printf("k_fft_res16 probe: %ld transforms, %d workgroups\n", batch, cus);
+  if (getenv("PROBE_NOXCHG")) {   // what do the LDS exchanges (and their barriers) cost the full kernel?
+    for (int round = 0; round < 3; round++) {
+      run<16>("full + stamps", data, slots, tabs, dbg, batch, cus);
+      run<4096 | 16>("no LDS exchange (garbage) + stamps", data, slots, tabs, dbg, batch, cus);
+      run<4 | 16>("no barriers (garbage) + stamps", data, slots, tabs, dbg, batch, cus);
+      run<4096 | 1 | 2 | 8 | 16>("no exchange, no global traffic", data, slots, tabs, dbg, batch, cus);
+      run<1 | 2 | 8 | 16>("no global traffic", data, slots, tabs, dbg, batch, cus);
+    }
+    return 0;
+  }
   if (getenv("PROBE_PACK")) {   // a pair-map phase behind phase 2, inside the launch
     for (int round = 0; round < 3; round++) {
       run<16>("full + stamps", data, slots, tabs, dbg, batch, cus);
