@@ -10,6 +10,8 @@ import opencl_fft_amd._lib as L
 new = L.lib()
 old = C.CDLL(sys.argv[1])
 for name, res, args in L.SYMBOLS:
+    if not hasattr(old, name):      # an older build: entry points added since are simply absent
+        continue
     f = getattr(old, name); f.restype = res; f.argtypes = args
 what = sys.argv[2] if len(sys.argv) > 2 else "rfft"
 rsize = int(what[4:]) if what.startswith("rfft") and len(what) > 4 else 16384   # rfft<size>: another packed real size
@@ -36,8 +38,9 @@ elif len(what) > 3:
     d = torch.rand((batch, n, 2), device="cuda") * 2 - 1
     unit = batch * n * 16
 else:
-    batch, d = 4096, torch.rand((4096, 65536, 2), device="cuda") * 2 - 1
-    unit = 4096 * 65536 * 16
+    batch = int(__import__("os").environ.get("AB_BATCH", "4096"))      # AB_BATCH: another batch of N = 65536 transforms
+    d = torch.rand((batch, 65536, 2), device="cuda") * 2 - 1
+    unit = batch * 65536 * 16
 libs = {"new": (new, plans(new)), "old": (old, plans(old))}
 if len(sys.argv) > 3 and sys.argv[3] == "swap":
     libs = dict(reversed(list(libs.items())))
