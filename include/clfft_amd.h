@@ -107,10 +107,10 @@ CLFA_API int clfa_rfft_transform(clfa_fft *plan, float *c, float *r, long batch)
 CLFA_API int clfa_fft_exec_dev(clfa_fft *plan, void *data, long batch, void *stream);
 /* the same from `src` to `dst` (extension).  The reference's device side is itself out of place — its `reorder` gathers
  * data1 -> data2 and the stages then run on data2, cl_fft.cpp:138-151 — and on MI355X a kernel that reads one buffer and
- * writes another is ~3 % faster than the same kernel in place: complex n = 65536 in batches (the
- * resident kernel) runs natively src -> dst; every other plan copies src to dst on the stream and transforms dst in
- * place (correct, one more pass).  src == dst is clfa_fft_exec_dev; partly overlapping buffers are CLFA_INVALID_VALUE.
- * `src` is left untouched. */
+ * writes another is ~3 % faster than the same kernel in place for n = 65536.  Every plan runs
+ * src -> dst natively, at the cost of the in-place call: the kernels read the source and write the destination, routes of
+ * several passes put their first pass there.  src == dst is clfa_fft_exec_dev; partly overlapping buffers, and buffers
+ * that are not a whole number of complex values apart, are CLFA_INVALID_VALUE.  `src` is left untouched. */
 CLFA_API int clfa_fft_exec_dev_oop(clfa_fft *plan, const void *src, void *dst, long batch, void *stream);
 /* The reference's protected members for subclasses (cl_fft.h:35-44): data1 / data2 = the object's own device buffers of one
  * transform each (n complex64; real plans: size floats), allocated on first request and released with the plan;

@@ -657,6 +657,79 @@ const char *clfa_fft_kernel_name(const clfa_fft *p) {
   return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R)) : name_fft_4step(p->logn);
 }
 
+// The body of every device-resident transform: `d` is read, the results go to d + off complex elements (off = 0: in
+// place; otherwise a destination that does not overlap the source, which is then left untouched).  Two-pass routes run
+// their FIRST pass from the source to the destination and the rest in place there.
+static int fft_exec(clfa_fft *p, cpx *d, long off, long batch, hipStream_t s) {
+  const bool scale = p->fwd;  // cl_fft.cpp:39-40: forward plans divide by N, inverse plans do not
+  cpx *o = d + off;
+  if (p->blue_m) {
+    const int n = p->n, m = p->blue_m;
+    cpx *work = (cpx *)p->blue_work.p;
+    const cpx *w = (const cpx *)p->blue_w.p, *bt = (const cpx *)p->blue_b.p;
+    cpx *src = d;
+    if (p->real && !p->fwd) {
+      HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, n, batch, s, off));   // -> the destination
+      src = o;
+    }
+    const long cb = (long)(p->blue_work.bytes / (sizeof(cpx) * (size_t)m));
+    for (long b0 = 0; b0 < batch; b0 += cb) {
+      const long nb = batch - b0 < cb ? batch - b0 : cb;
+      HIP_TRY(launch_blue_pre(src + b0 * (long)n, w, work, n, m, nb, s));
+      int e = fft_exec(p->blue_f, work, 0, nb, s);
+      if (e) return e;
+      HIP_TRY(launch_blue_mul(work, bt, m, nb, s));
+      if ((e = fft_exec(p->blue_i, work, 0, nb, s))) return e;
+      HIP_TRY(launch_blue_post(work, w, o + b0 * (long)n, n, m, scale ? 1.0f / (float)n : 1.0f, nb, s));
+    }
+    if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(o, p->tabs.w2, n, batch, s));
+    return CLFA_SUCCESS;
+  }
+  const bool spread = p->real && batch <= p->spread_below;   // a few transforms: one workgroup each would be slower
+  if (p->rlds15 && !spread) {
+    HIP_TRY(launch_rfft_lds15(p->fwd, d, p->tabs, batch, p->di, s, off));
+    return CLFA_SUCCESS;
+  }
+  if (p->r2x13 && !spread) {
+    FftTables t2 = p->tabs;
+    t2.half = (const cpx *)p->half2.p;
+    HIP_TRY(launch_rfft_2x13(p->fwd, d, t2, batch, p->di, s, off));
+    return CLFA_SUCCESS;
+  }
+  if (p->c2x13 && batch * 4 > p->di.num_cus) {   // (fewer transforms: spread over the four-step column / row kernels)
+    FftTables t2 = p->tabs;
+    t2.half = (const cpx *)p->half2.p;
+    HIP_TRY(launch_cfft_2x13(p->fwd, scale, d, t2, batch, p->di, s, off));
+    return CLFA_SUCCESS;
+  }
+  if (p->logn <= kLdsMaxLog) {
+    int mode = !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R);
+    HIP_TRY(launch_fft_lds(p->logn, p->fwd, mode, scale, d, p->tabs, batch, p->di, s, off));
+    return CLFA_SUCCESS;
+  }
+  // a complex transform, with the reference's pack / unpack as a pass of its own for the packed real sizes that have no
+  // fused kernel (and for a few transforms of those that have one)
+  cpx *src = d;
+  long toff = off;   // the transform's own offset: the inverse real route is at the destination already
+  if (p->real && !p->fwd) {
+    HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, p->n, batch, s, off));
+    src = o;
+    toff = 0;
+  }
+  if (p->logn > kMaxLog) {
+    const long cb = (long)(p->scratch.bytes / (sizeof(cpx) * (size_t)p->n));
+    for (long b0 = 0; b0 < batch; b0 += cb) {
+      const long nb = batch - b0 < cb ? batch - b0 : cb;
+      HIP_TRY(launch_fft_big(p->big, p->fwd, scale, src + b0 * (long)p->n, src + toff + b0 * (long)p->n, (cpx *)p->scratch.p,
+                             (cpx *)p->scratch2.p, (const cpx *)p->bigtabs.p, p->tabs, nb, p->di, s));
+    }
+  } else {
+    HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, src, (cpx *)p->scratch.p, p->tabs, batch, p->di, s, toff));
+  }
+  if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(o, p->tabs.w2, p->n, batch, s));
+  return CLFA_SUCCESS;
+}
+
 int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
@@ -665,62 +738,7 @@ int clfa_fft_exec_dev(clfa_fft *p, void *data, long batch, void *stream) {
   ENTER_DEVICE(p->di.device);
   hipStream_t s = (hipStream_t)stream;  // NULL is the HIP default stream
   HIP_TRY(p->order.use(s));
-  cpx *d = (cpx *)data;
-  const bool scale = p->fwd;  // cl_fft.cpp:39-40: forward plans divide by N, inverse plans do not
-  if (p->blue_m) {
-    const int n = p->n, m = p->blue_m;
-    cpx *work = (cpx *)p->blue_work.p;
-    const cpx *w = (const cpx *)p->blue_w.p, *bt = (const cpx *)p->blue_b.p;
-    if (p->real && !p->fwd) HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, n, batch, s));
-    const long cb = (long)(p->blue_work.bytes / (sizeof(cpx) * (size_t)m));
-    for (long b0 = 0; b0 < batch; b0 += cb) {
-      const long nb = batch - b0 < cb ? batch - b0 : cb;
-      cpx *x = d + b0 * (long)n;
-      HIP_TRY(launch_blue_pre(x, w, work, n, m, nb, s));
-      int e = clfa_fft_exec_dev(p->blue_f, work, nb, s);
-      if (e) return e;
-      HIP_TRY(launch_blue_mul(work, bt, m, nb, s));
-      if ((e = clfa_fft_exec_dev(p->blue_i, work, nb, s))) return e;
-      HIP_TRY(launch_blue_post(work, w, x, n, m, scale ? 1.0f / (float)n : 1.0f, nb, s));
-    }
-    if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, n, batch, s));
-    return CLFA_SUCCESS;
-  }
-  const bool spread = p->real && batch <= p->spread_below;   // a few transforms: one workgroup each would be slower
-  if (p->rlds15 && !spread) {
-    HIP_TRY(launch_rfft_lds15(p->fwd, d, p->tabs, batch, p->di, s));
-    return CLFA_SUCCESS;
-  }
-  if (p->r2x13 && !spread) {
-    FftTables t2 = p->tabs;
-    t2.half = (const cpx *)p->half2.p;
-    HIP_TRY(launch_rfft_2x13(p->fwd, d, t2, batch, p->di, s));
-    return CLFA_SUCCESS;
-  }
-  if (p->c2x13 && batch * 4 > p->di.num_cus) {   // (fewer transforms: spread over the four-step column / row kernels)
-    FftTables t2 = p->tabs;
-    t2.half = (const cpx *)p->half2.p;
-    HIP_TRY(launch_cfft_2x13(p->fwd, scale, d, t2, batch, p->di, s));
-    return CLFA_SUCCESS;
-  }
-  if (p->logn <= kLdsMaxLog) {
-    int mode = !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R);
-    HIP_TRY(launch_fft_lds(p->logn, p->fwd, mode, scale, d, p->tabs, batch, p->di, s));
-    return CLFA_SUCCESS;
-  }
-  if (p->real && !p->fwd) HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, p->n, batch, s));
-  if (p->logn > kMaxLog) {
-    const long cb = (long)(p->scratch.bytes / (sizeof(cpx) * (size_t)p->n));
-    for (long b0 = 0; b0 < batch; b0 += cb) {
-      const long nb = batch - b0 < cb ? batch - b0 : cb;
-      HIP_TRY(launch_fft_big(p->big, p->fwd, scale, d + b0 * (long)p->n, (cpx *)p->scratch.p, (cpx *)p->scratch2.p,
-                             (const cpx *)p->bigtabs.p, p->tabs, nb, p->di, s));
-    }
-  } else {
-    HIP_TRY(launch_fft_4step(p->logn, p->fwd, scale, d, (cpx *)p->scratch.p, p->tabs, batch, p->di, s));
-  }
-  if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(d, p->tabs.w2, p->n, batch, s));
-  return CLFA_SUCCESS;
+  return fft_exec(p, (cpx *)data, 0, batch, s);
 }
 
 int clfa_fft_exec_dev_oop(clfa_fft *p, const void *src, void *dst, long batch, void *stream) {
@@ -732,15 +750,13 @@ int clfa_fft_exec_dev_oop(clfa_fft *p, const void *src, void *dst, long batch, v
   const size_t bytes = sizeof(cpx) * (size_t)p->n * (size_t)batch;   // real plans: n = size / 2 packed bins = size floats
   const char *a = (const char *)src, *b = (const char *)dst;
   if (a < b + bytes && b < a + bytes) return CLFA_INVALID_VALUE;     // partly overlapping
+  if ((b - a) % (long)sizeof(cpx)) return CLFA_INVALID_VALUE;         // the two buffers a whole number of complex values apart
   ENTER_DEVICE(p->di.device);
   hipStream_t s = (hipStream_t)stream;
-  if (!p->real && !p->blue_m && p->logn == 16 && batch * 4 > p->di.num_cus) {
-    HIP_TRY(p->order.use(s));
-    HIP_TRY(launch_fft_res16(p->fwd, p->fwd, (const cpx *)src, (cpx *)dst, (cpx *)p->scratch.p, p->tabs.res16, batch, p->di, s));
-    return CLFA_SUCCESS;
-  }
-  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
-  return clfa_fft_exec_dev(p, dst, batch, stream);
+  HIP_TRY(p->order.use(s));
+  // every kernel reads the source and writes the destination (the kernels take the distance between the two); the source
+  // is never written — also not by the routes of several passes, whose first pass already lands in the destination
+  return fft_exec(p, (cpx *)const_cast<void *>(src), (long)((b - a) / (long)sizeof(cpx)), batch, s);
 }
 
 int clfa_fft_device_buffers(clfa_fft *p, void **data1, void **data2, void **commands) {

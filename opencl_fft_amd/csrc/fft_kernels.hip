@@ -182,7 +182,8 @@ __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const c
 template <int LOGN, bool FWD, int MODE, bool SCALE>
 __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k_fft_lds(cpx *__restrict__ data,
                                                               const cpx *__restrict__ tab_g,
-                                                              const cpx *__restrict__ w2_g, long batch) {
+                                                              const cpx *__restrict__ w2_g, long batch, long out_off) {
+  // out_off: results go to data + out_off (complex elements; 0 = in place, else a disjoint destination: clfa_fft_exec_dev_oop)
   using G = LdsGeom<LOGN>;
   constexpr int N = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
   // twiddles in LDS: half table W_n^k (k < n/2); n = 8192: the lane-addressed tables of LaneTab13
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     // loaded the same input in the same instruction as its owner and store bit-identical output.
     (void)active;
     [[maybe_unused]] XferBuf xo{};
+    x += out_off;   // every access from here on is a store of this transform's results
     if constexpr (kLdsBufAddr<LOGN, MODE, FWD>) xo = xfer_buf<LOGN>(x, t);
     if constexpr (MODE == MODE_R2C && PAIRED) {
       // fused reference `conv` (cl_fft.cpp:178-191): both bins of every pair are in this lane's registers
@@ -499,7 +501,7 @@ __device__ __forceinline__ void st_nt16(cpx *p, f4v v) {
 // pass pairs, which no 16-point-per-lane form of a 4096-point transform does), 256 lanes, the half table in LDS
 template <int LOGC, bool FWD, bool SCALE, int LOGE = 4>
 __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
-                                                                    const cpx *__restrict__ w2_g, long batch) {
+                                                                    const cpx *__restrict__ w2_g, long batch, long out_off) {
   constexpr int LOGN = LOGC, E = 1 << LOGE, M = 1 << LOGC, T = M / E, R = 1 << pass_rem_logr(LOGC, LOGE);
   constexpr bool LANE = kLdsTwoLevel(LOGC);   // lane-addressed tables (8192 / 16384 points) or the half table W_M^k
   constexpr int NTAB = LANE ? kLane13Lds : M / 2;
@@ -529,6 +531,7 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
     }();
     const cpx g0 = cmul(h0, h0);   // W_2M^tid
     cpx *x = data + b * (long)(2 * M);
+    cpx *xs = x + out_off;   // where the results go (out_off = 0: in place)
     const XferBuf xo{__builtin_amdgcn_make_buffer_rsrc(x, 0, 0x7fffffff, 0x00020000), t * 8, (T - t) * 8};
     cpx va[E], vb[E];
     if constexpr (FWD) {
@@ -561,7 +564,7 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
       for (int k = 0; k < E / 2; k++) {
         // (flat addresses for the forward kernel's stores: buffer-addressed they were measured 2 % slower)
         rfft2x_fwd_slot<LOGC>(t, k / R, k % R, pair_index<LOGN, LOGE>(t, k / R, k % R), ai[k], aj[k], bi[k], bj[k], g0, h0,
-                              [&](int pos, cpx v) { st_nt(x + pos, v); });
+                              [&](int pos, cpx v) { st_nt(xs + pos, v); });
         __builtin_amdgcn_sched_barrier(0);   // slot by slot: hoisted, the eight slots' twiddles spill
       }
     } else {
@@ -595,25 +598,27 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
       dif_gather_padded<LOGN, LOGE, L1>(vb, t, xb);
       wg_passes_dif_pair<LOGN, LOGE, L1, false>(va, vb, t, tab, xb);
 #pragma unroll
-      for (int e = 0; e < E; e++) st_nt16(x + 2 * (t + T * e), f4v{va[e].x, va[e].y, vb[e].x, vb[e].y});
+      for (int e = 0; e < E; e++) st_nt16(xs + 2 * (t + T * e), f4v{va[e].x, va[e].y, vb[e].x, vb[e].y});
     }
   }
 }
 
-hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
+hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s,
+                             long out_off) {
   if (batch <= 0) return hipSuccess;
   const int grid = (int)(batch < di.num_cus ? batch : di.num_cus);   // one 1024-lane workgroup per CU
-  if (fwd) hipLaunchKernelGGL((k_rfft_2x<14, true, true>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
-  else hipLaunchKernelGGL((k_rfft_2x<14, false, false>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch);
+  if (fwd) hipLaunchKernelGGL((k_rfft_2x<14, true, true>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch, out_off);
+  else hipLaunchKernelGGL((k_rfft_2x<14, false, false>), dim3(grid), dim3(1024), 0, s, data, t.half, t.w2, batch, out_off);
   return hipGetLastError();
 }
 // real size 32768: t.half = the n = 8192 lane tables (kLane13Size), t.w2 = the plan's r2c table (16384 entries)
-hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
+hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s,
+                            long out_off) {
   if (batch <= 0) return hipSuccess;
   const long cap = 2L * di.num_cus;   // two 512-lane workgroups per CU
   const int grid = (int)(batch < cap ? batch : cap);
-  if (fwd) hipLaunchKernelGGL((k_rfft_2x<13, true, true>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch);
-  else hipLaunchKernelGGL((k_rfft_2x<13, false, false>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch);
+  if (fwd) hipLaunchKernelGGL((k_rfft_2x<13, true, true>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch, out_off);
+  else hipLaunchKernelGGL((k_rfft_2x<13, false, false>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch, out_off);
   return hipGetLastError();
 }
 
@@ -629,7 +634,7 @@ hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch,
 // four-step kernel before choosing)
 template <int LOGC, bool FWD, bool SCALE>
 __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_cfft_2x(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
-                                                                 long batch) {
+                                                                 long batch, long out_off) {
   using G = LdsGeom<LOGC>;
   constexpr int LOGN = LOGC, LOGE = 4, E = 16, M = 1 << LOGC, T = M / E;
   __shared__ cpx s_tab[kLane13Lds];
@@ -683,8 +688,8 @@ __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_cfft_2x(cpx *__restrict
         o0 = cscale(o0, inv);
         o1 = cscale(o1, inv);
       }
-      st_nt(x + t + T * e, o0);
-      st_nt(x + M + t + T * e, o1);
+      st_nt(x + out_off + t + T * e, o0);
+      st_nt(x + out_off + M + t + T * e, o1);
       __builtin_amdgcn_sched_barrier(0);   // element by element: hoisted, the sixteen twiddles spill
     }
   }
@@ -692,20 +697,20 @@ __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_cfft_2x(cpx *__restrict
 
 template <int LOGC>
 static hipError_t launch_cfft_2x_n(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
-                                   hipStream_t s) {
+                                   hipStream_t s, long out_off) {
   if (batch <= 0) return hipSuccess;
   constexpr int T = (1 << LOGC) / 16;
   const long cap = (LOGC == 13 ? 2L : 1L) * di.num_cus;   // two 512-lane workgroups per CU, or one of 1024 lanes
   const int grid = (int)(batch < cap ? batch : cap);
-  if (fwd && scale) hipLaunchKernelGGL((k_cfft_2x<LOGC, true, true>), dim3(grid), dim3(T), 0, s, data, t.half, batch);
-  else if (fwd) hipLaunchKernelGGL((k_cfft_2x<LOGC, true, false>), dim3(grid), dim3(T), 0, s, data, t.half, batch);
-  else if (!scale) hipLaunchKernelGGL((k_cfft_2x<LOGC, false, false>), dim3(grid), dim3(T), 0, s, data, t.half, batch);
+  if (fwd && scale) hipLaunchKernelGGL((k_cfft_2x<LOGC, true, true>), dim3(grid), dim3(T), 0, s, data, t.half, batch, out_off);
+  else if (fwd) hipLaunchKernelGGL((k_cfft_2x<LOGC, true, false>), dim3(grid), dim3(T), 0, s, data, t.half, batch, out_off);
+  else if (!scale) hipLaunchKernelGGL((k_cfft_2x<LOGC, false, false>), dim3(grid), dim3(T), 0, s, data, t.half, batch, out_off);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
-                            hipStream_t s) {
-  return launch_cfft_2x_n<13>(fwd, scale, data, t, batch, di, s);
+                            hipStream_t s, long out_off) {
+  return launch_cfft_2x_n<13>(fwd, scale, data, t, batch, di, s, out_off);
 }
 
 // ---------------------------------------------------------------------------------
@@ -717,7 +722,7 @@ hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t,
 // rows of 256 elements, parked in the per-transform padded LDS buffers at their natural positions, and
 // picked up from there in the owning lanes' order (pass_gather_padded); results go back the same way.
 template <int LOGN, bool FWD, int MODE, bool SCALE>
-__global__ __launch_bounds__(256) void k_fft_small(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
+__global__ __launch_bounds__(256) void k_fft_small(cpx *__restrict__ data, long out_off, const cpx *__restrict__ tab_g,
                                                    const cpx *__restrict__ w2_g, long batch) {
   using G = LdsGeom<LOGN>;
   constexpr int N = G::N, E = G::E, T = G::T, FPW = G::FPW, CHUNK = FPW * N;
@@ -803,11 +808,11 @@ __global__ __launch_bounds__(256) void k_fft_small(cpx *__restrict__ data, const
     const bool full = base + CHUNK <= total;   // uniform
     if (full) {
 #pragma unroll
-      for (int e = 0; e < E; e++) st_nt(data + base + tid + 256 * e, park[e * PARK_STEP]);
+      for (int e = 0; e < E; e++) st_nt(data + out_off + base + tid + 256 * e, park[e * PARK_STEP]);
     } else {
 #pragma unroll
       for (int e = 0; e < E; e++)
-        if (base + tid + 256 * e < total) data[base + tid + 256 * e] = park[e * PARK_STEP];
+        if (base + tid + 256 * e < total) data[out_off + base + tid + 256 * e] = park[e * PARK_STEP];
     }
     __syncthreads();   // the parked results are out before the next chunk is parked
 #pragma unroll
@@ -816,7 +821,7 @@ __global__ __launch_bounds__(256) void k_fft_small(cpx *__restrict__ data, const
 }
 
 template <int LOGN, bool FWD, int MODE, bool SCALE>
-static hipError_t launch_small_one(cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s) {
+static hipError_t launch_small_one(cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s, long out_off) {
   using G = LdsGeom<LOGN>;
   long groups = (batch + G::FPW - 1) / G::FPW;
   static int occ = 0;
@@ -831,13 +836,13 @@ static hipError_t launch_small_one(cpx *data, const FftTables &t, long batch, co
   long cap = (long)di.num_cus * occ;
   int grid = (int)(groups < cap ? groups : cap);
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_fft_small<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(256), 0, s, data, t.half, t.w2, batch);
+  hipLaunchKernelGGL((k_fft_small<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(256), 0, s, data, out_off, t.half, t.w2, batch);
   return hipGetLastError();
 }
 
 template <int LOGN, bool FWD, int MODE, bool SCALE>
 static hipError_t launch_lds_one(cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
-                                 hipStream_t s) {
+                                 hipStream_t s, long out_off) {
   using G = LdsGeom<LOGN>;
   long groups = (batch + G::FPW - 1) / G::FPW;
   // persistent grid: exactly the workgroups that are resident at once (occupancy x CUs), each
@@ -856,20 +861,20 @@ static hipError_t launch_lds_one(cpx *data, const FftTables &t, long batch, cons
   int grid = (int)(groups < cap ? groups : cap);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_fft_lds<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(G::WG), 0, s, data, t.half, t.w2,
-                     batch);
+                     batch, out_off);
   return hipGetLastError();
 }
 
 template <int LOGN>
 static hipError_t launch_lds_n(bool fwd, int mode, bool scale, cpx *data, const FftTables &t, long batch,
-                               const DeviceInfo &di, hipStream_t s) {
+                               const DeviceInfo &di, hipStream_t s, long out_off) {
 #define CLFA_CASE(F, M, S)                                                                                     \
   if (fwd == F && mode == M && scale == S) {                                                                   \
     /* sub-64-byte rows per transform (and the packed real transforms up to 256 bins, whose pair maps  */     \
     /* store 8-byte pieces): coalesced staging through LDS                                              */     \
     if constexpr (LOGN >= 2 && (LOGN <= 6 || (M != MODE_C2C && LOGN <= 8)))                                     \
-      return launch_small_one<LOGN, F, M, S>(data, t, batch, di, s);                                           \
-    else return launch_lds_one<LOGN, F, M, S>(data, t, batch, di, s);                                          \
+      return launch_small_one<LOGN, F, M, S>(data, t, batch, di, s, out_off);                                  \
+    else return launch_lds_one<LOGN, F, M, S>(data, t, batch, di, s, out_off);                                 \
   }
   CLFA_CASE(true, MODE_C2C, true)
   CLFA_CASE(true, MODE_C2C, false)
@@ -881,12 +886,12 @@ static hipError_t launch_lds_n(bool fwd, int mode, bool scale, cpx *data, const 
 }
 
 hipError_t launch_fft_lds(int logn, bool fwd, int mode, bool scale, cpx *data, const FftTables &t,
-                          long batch, const DeviceInfo &di, hipStream_t s) {
+                          long batch, const DeviceInfo &di, hipStream_t s, long out_off) {
   if (batch <= 0) return hipSuccess;
   switch (logn) {
 #define CLFA_N(L) \
   case L:         \
-    return launch_lds_n<L>(fwd, mode, scale, data, t, batch, di, s);
+    return launch_lds_n<L>(fwd, mode, scale, data, t, batch, di, s, out_off);
     CLFA_N(1) CLFA_N(2) CLFA_N(3) CLFA_N(4) CLFA_N(5) CLFA_N(6) CLFA_N(7) CLFA_N(8) CLFA_N(9) CLFA_N(10)
     CLFA_N(11) CLFA_N(12) CLFA_N(13)
 #undef CLFA_N
@@ -1102,7 +1107,7 @@ __device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__
 // intermediate for n = 65536 — stays in LDS between the phases instead of going through the scratch
 template <int LOGN, bool FWD, bool SCALE>
 __global__ __launch_bounds__(512) void k_fft_4step(cpx *__restrict__ data, cpx *__restrict__ scratch,
-                                                           const cpx *__restrict__ tabs_g, long batch) {
+                                                           const cpx *__restrict__ tabs_g, long batch, long out_off) {
   using G = FourGeom<LOGN>;
   constexpr int NSLICE = 2;        // two 256-lane slices per workgroup
   constexpr bool NT = true;        // non-temporal input loads / output stores
@@ -1214,10 +1219,10 @@ __global__ __launch_bounds__(512) void k_fft_4step(cpx *__restrict__ data, cpx *
           asm volatile("" : "+v"(lo_));
           four_load2_rows<LOGN>(vn, s_rows, slice, lo_);
           if constexpr (r + 1 < RRB) {
-            four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, slice + NSLICE * r, lo_, ftab2, sx, nullptr,
+            four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x + out_off, slice + NSLICE * r, lo_, ftab2, sx, nullptr,
                                                      [&]() { dump(std::integral_constant<int, r + 1>()); });
           } else {
-            four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, slice + NSLICE * r, lo_, ftab2, sx);
+            four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x + out_off, slice + NSLICE * r, lo_, ftab2, sx);
           }
 #pragma unroll
           for (int e = 0; e < 16; e++) v[e] = vn[e];
@@ -1236,7 +1241,7 @@ __global__ __launch_bounds__(512) void k_fft_4step(cpx *__restrict__ data, cpx *
         int lo_ = l;
         asm volatile("" : "+v"(lo_));
         four_load2<LOGN, false>(vn, mid, rb + NSLICE, lo_);
-        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, rb, lo_, ftab2, sx);
+        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x + out_off, rb, lo_, ftab2, sx);
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           asm volatile("" : "+v"(vn[e]));
@@ -1250,7 +1255,7 @@ __global__ __launch_bounds__(512) void k_fft_4step(cpx *__restrict__ data, cpx *
         long bn = b + gridDim.x;
         bn = bn < batch ? bn : batch - 1;
         four_load1<LOGN, NT ? 1 : 0>(vnext, data + bn * (long)G::N, slice, lo_);
-        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x, G::NRB - NSLICE + slice, lo_, ftab2, sx);
+        four_body2<LOGN, FWD, SCALE, NT ? 1 : 0>(v, x + out_off, G::NRB - NSLICE + slice, lo_, ftab2, sx);
       }
       __syncthreads();
     }
@@ -1291,42 +1296,42 @@ int fourstep_grid(const DeviceInfo &di) { return di.num_cus; }   // one 512-lane
 
 template <int LOGN, bool FWD, bool SCALE>
 static hipError_t launch_4step_v(cpx *data, cpx *scratch, const FftTables &t, long batch, const DeviceInfo &di,
-                                 hipStream_t s) {
+                                 hipStream_t s, long out_off) {
   int grid = fourstep_grid(di);
   if (batch * 4 <= grid && batch <= 65535) {
     // few transforms: spread each over its column / row blocks (scratch holds `grid` transforms)
     using G = FourGeom<LOGN>;
     hipLaunchKernelGGL((k_fft_4step_cols<LOGN, FWD>), dim3(G::NCB, (unsigned)batch), dim3(256), 0, s, data, scratch, t.four);
-    hipLaunchKernelGGL((k_fft_4step_rows<LOGN, FWD, SCALE>), dim3(G::NRB, (unsigned)batch), dim3(256), 0, s, data, scratch,
-                       t.four);
+    hipLaunchKernelGGL((k_fft_4step_rows<LOGN, FWD, SCALE>), dim3(G::NRB, (unsigned)batch), dim3(256), 0, s, data + out_off,
+                       scratch, t.four);
     return hipGetLastError();
   }
   if constexpr (LOGN == 16) {
     // n = 65536: the resident kernel (fft_resident.hip); `scratch` provides its per-workgroup slots
-    return launch_fft_res16(FWD, SCALE, data, data, scratch, t.res16, batch, di, s);
+    return launch_fft_res16(FWD, SCALE, data, data + out_off, scratch, t.res16, batch, di, s);
   } else {
     if (batch < grid) grid = (int)batch;
-    hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE>), dim3(grid), dim3(512), 0, s, data, scratch, t.four, batch);
+    hipLaunchKernelGGL((k_fft_4step<LOGN, FWD, SCALE>), dim3(grid), dim3(512), 0, s, data, scratch, t.four, batch, out_off);
     return hipGetLastError();
   }
 }
 
 template <int LOGN>
 static hipError_t launch_4step_n(bool fwd, bool scale, cpx *data, cpx *scratch, const FftTables &t, long batch,
-                                 const DeviceInfo &di, hipStream_t s) {
-  if (fwd && scale) return launch_4step_v<LOGN, true, true>(data, scratch, t, batch, di, s);
-  if (fwd && !scale) return launch_4step_v<LOGN, true, false>(data, scratch, t, batch, di, s);
-  if (!fwd && !scale) return launch_4step_v<LOGN, false, false>(data, scratch, t, batch, di, s);
+                                 const DeviceInfo &di, hipStream_t s, long out_off) {
+  if (fwd && scale) return launch_4step_v<LOGN, true, true>(data, scratch, t, batch, di, s, out_off);
+  if (fwd && !scale) return launch_4step_v<LOGN, true, false>(data, scratch, t, batch, di, s, out_off);
+  if (!fwd && !scale) return launch_4step_v<LOGN, false, false>(data, scratch, t, batch, di, s, out_off);
   return hipErrorInvalidValue;
 }
 
 hipError_t launch_fft_4step(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, const FftTables &t, long batch,
-                            const DeviceInfo &di, hipStream_t s) {
+                            const DeviceInfo &di, hipStream_t s, long out_off) {
   if (batch <= 0) return hipSuccess;
   switch (logn) {
-    case 14: return launch_4step_n<14>(fwd, scale, data, scratch, t, batch, di, s);
-    case 15: return launch_4step_n<15>(fwd, scale, data, scratch, t, batch, di, s);
-    case 16: return launch_4step_n<16>(fwd, scale, data, scratch, t, batch, di, s);
+    case 14: return launch_4step_n<14>(fwd, scale, data, scratch, t, batch, di, s, out_off);
+    case 15: return launch_4step_n<15>(fwd, scale, data, scratch, t, batch, di, s, out_off);
+    case 16: return launch_4step_n<16>(fwd, scale, data, scratch, t, batch, di, s, out_off);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1421,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_big_transpose(const cpx *__restrict__ s
 }
 
 template <int LOGN1>
-static hipError_t launch_big_n1(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, cpx *scratch2,
+static hipError_t launch_big_n1(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *out, cpx *scratch, cpx *scratch2,
                                 const cpx *bigtabs, const FftTables &sub, long batch, const DeviceInfo &di,
                                 hipStream_t s) {
   constexpr int N1 = 1 << LOGN1, T1 = N1 / 16, C1 = 256 / T1, TK1 = N1 < 64 ? N1 : 64, TK2 = 4096 / TK1;
@@ -1431,12 +1436,12 @@ static hipError_t launch_big_n1(const BigGeom &g, bool fwd, bool scale, cpx *dat
   else hipLaunchKernelGGL((k_big_cols<LOGN1, false>), gc, dim3(256), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (g.logn2 <= kLdsMaxLog) e = launch_fft_lds(g.logn2, fwd, MODE_C2C, false, scratch, sub, batch * N1, di, s);
-  else e = launch_fft_4step(g.logn2, fwd, false, scratch, scratch2, sub, batch * N1, di, s);
+  if (g.logn2 <= kLdsMaxLog) e = launch_fft_lds(g.logn2, fwd, MODE_C2C, false, scratch, sub, batch * N1, di, s, 0);
+  else e = launch_fft_4step(g.logn2, fwd, false, scratch, scratch2, sub, batch * N1, di, s, 0);
   if (e != hipSuccess) return e;
   const float inv_n = 1.0f / (float)(1L << g.logn);
-  if (scale) hipLaunchKernelGGL((k_big_transpose<LOGN1, true>), gt, dim3(256), 0, s, scratch, data, g.logn2, inv_n);
-  else hipLaunchKernelGGL((k_big_transpose<LOGN1, false>), gt, dim3(256), 0, s, scratch, data, g.logn2, inv_n);
+  if (scale) hipLaunchKernelGGL((k_big_transpose<LOGN1, true>), gt, dim3(256), 0, s, scratch, out, g.logn2, inv_n);
+  else hipLaunchKernelGGL((k_big_transpose<LOGN1, false>), gt, dim3(256), 0, s, scratch, out, g.logn2, inv_n);
   return hipGetLastError();
 }
 
@@ -1632,7 +1637,7 @@ static hipError_t launch_big2_rows(const BigGeom &g, bool fwd, bool scale, const
   else hipLaunchKernelGGL((k_big2_rows<LOGN2, false, false>), grid, dim3(1 << LOGN2), 0, s, scratch, data, half2, g.logn1, inv_n);
   return hipGetLastError();
 }
-static hipError_t launch_fft_big2(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, const cpx *bigtabs,
+static hipError_t launch_fft_big2(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *out, cpx *scratch, const cpx *bigtabs,
                                   const FftTables &sub, long batch, hipStream_t s) {
   hipError_t e;
   switch (g.logn1) {
@@ -1649,13 +1654,13 @@ static hipError_t launch_fft_big2(const BigGeom &g, bool fwd, bool scale, cpx *d
   }
   if (e != hipSuccess) return e;
   switch (g.logn2) {
-    case 9: return launch_big2_rows<9>(g, fwd, scale, scratch, data, sub.half, batch, s);
+    case 9: return launch_big2_rows<9>(g, fwd, scale, scratch, out, sub.half, batch, s);
     case 10: {   // ... and the 1024-point rows
       const dim3 grid((1 << g.logn1) / 16, (unsigned)batch);
       const float inv_n = 1.0f / (float)(1L << g.logn);
-      if (fwd && scale) hipLaunchKernelGGL((k_big2_rows_2x<true, true>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
-      else if (fwd) hipLaunchKernelGGL((k_big2_rows_2x<true, false>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
-      else hipLaunchKernelGGL((k_big2_rows_2x<false, false>), grid, dim3(512), 0, s, scratch, data, sub.half, g.logn1, inv_n);
+      if (fwd && scale) hipLaunchKernelGGL((k_big2_rows_2x<true, true>), grid, dim3(512), 0, s, scratch, out, sub.half, g.logn1, inv_n);
+      else if (fwd) hipLaunchKernelGGL((k_big2_rows_2x<true, false>), grid, dim3(512), 0, s, scratch, out, sub.half, g.logn1, inv_n);
+      else hipLaunchKernelGGL((k_big2_rows_2x<false, false>), grid, dim3(512), 0, s, scratch, out, sub.half, g.logn1, inv_n);
       return hipGetLastError();
     }
     default: return hipErrorInvalidValue;
@@ -1663,16 +1668,16 @@ static hipError_t launch_fft_big2(const BigGeom &g, bool fwd, bool scale, cpx *d
 }
 
 // scratch: `batch` transforms (the caller chunks); scratch2: the four-step workspace when N2 > 8192
-hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, cpx *scratch2,
+hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *out, cpx *scratch, cpx *scratch2,
                           const cpx *bigtabs, const FftTables &sub, long batch, const DeviceInfo &di, hipStream_t s) {
   if (batch <= 0) return hipSuccess;
   if (batch > 65535) return hipErrorInvalidValue;
-  if (g.logn <= 20) return launch_fft_big2(g, fwd, scale, data, scratch, bigtabs, sub, batch, s);
+  if (g.logn <= 20) return launch_fft_big2(g, fwd, scale, data, out, scratch, bigtabs, sub, batch, s);
   switch (g.logn1) {
-    case 5: return launch_big_n1<5>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
-    case 6: return launch_big_n1<6>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
-    case 7: return launch_big_n1<7>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
-    case 8: return launch_big_n1<8>(g, fwd, scale, data, scratch, scratch2, bigtabs, sub, batch, di, s);
+    case 5: return launch_big_n1<5>(g, fwd, scale, data, out, scratch, scratch2, bigtabs, sub, batch, di, s);
+    case 6: return launch_big_n1<6>(g, fwd, scale, data, out, scratch, scratch2, bigtabs, sub, batch, di, s);
+    case 7: return launch_big_n1<7>(g, fwd, scale, data, out, scratch, scratch2, bigtabs, sub, batch, di, s);
+    case 8: return launch_big_n1<8>(g, fwd, scale, data, out, scratch, scratch2, bigtabs, sub, batch, di, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1683,39 +1688,43 @@ hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx
 
 // reference conv (cl_fft.cpp:178-191) over a batch; thread per pair
 __global__ __launch_bounds__(256) void k_r2c_pack(cpx *__restrict__ data, const cpx *__restrict__ w2, int m,
-                                                  long total_pairs) {
+                                                  long total_pairs, long out_off) {
   const int hp = m / 2;
   for (long g = blockIdx.x * 256L + threadIdx.x; g < total_pairs; g += (long)gridDim.x * 256) {
     long b = g / hp;
     int i = (int)(g % hp);
-    cpx *c = data + b * m;
+    const cpx *c = data + b * m;
+    cpx *o = data + b * m + out_off;   // out_off = 0: in place
     if (i == 0) {
       cpx z = c[0];
-      c[0] = mk((z.x + z.y) * .5f, (z.x - z.y) * .5f);
+      o[0] = mk((z.x + z.y) * .5f, (z.x - z.y) * .5f);
+      if (out_off) o[hp] = c[hp];   // the bin the reference never visits (cl_fft.cpp:278) travels as it is
     } else {
       cpx oi, oj;
       r2c_pair(c[i], c[m - i], w2[i], oi, oj);
-      c[i] = oi;
-      c[m - i] = oj;
+      o[i] = oi;
+      o[m - i] = oj;
     }
   }
 }
 // reference iconv (cl_fft.cpp:192-205)
 __global__ __launch_bounds__(256) void k_c2r_unpack(cpx *__restrict__ data, const cpx *__restrict__ w2, int m,
-                                                    long total_pairs) {
+                                                    long total_pairs, long out_off) {
   const int hp = m / 2;
   for (long g = blockIdx.x * 256L + threadIdx.x; g < total_pairs; g += (long)gridDim.x * 256) {
     long b = g / hp;
     int i = (int)(g % hp);
-    cpx *c = data + b * m;
+    const cpx *c = data + b * m;
+    cpx *o = data + b * m + out_off;
     if (i == 0) {
       cpx z = c[0];
-      c[0] = mk(z.x + z.y, z.x - z.y);
+      o[0] = mk(z.x + z.y, z.x - z.y);
+      if (out_off) o[hp] = c[hp];
     } else {
       cpx oi, oj;
       c2r_pair(c[i], c[m - i], w2[i], oi, oj);
-      c[i] = oi;
-      c[m - i] = oj;
+      o[i] = oi;
+      o[m - i] = oj;
     }
   }
 }
@@ -1727,16 +1736,16 @@ static int grid_for(long items) {
   return (int)g;
 }
 
-hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s) {
+hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s, long out_off) {
   long pairs = batch * (m / 2);
   if (pairs <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_r2c_pack, dim3(grid_for(pairs)), dim3(256), 0, s, data, w2, m, pairs);
+  hipLaunchKernelGGL(k_r2c_pack, dim3(grid_for(pairs)), dim3(256), 0, s, data, w2, m, pairs, out_off);
   return hipGetLastError();
 }
-hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s) {
+hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s, long out_off) {
   long pairs = batch * (m / 2);
   if (pairs <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_c2r_unpack, dim3(grid_for(pairs)), dim3(256), 0, s, data, w2, m, pairs);
+  hipLaunchKernelGGL(k_c2r_unpack, dim3(grid_for(pairs)), dim3(256), 0, s, data, w2, m, pairs, out_off);
   return hipGetLastError();
 }
 

@@ -35,26 +35,30 @@ struct DeviceInfo {
 
 // single-workgroup LDS FFT, n = 2^logn <= 2^kLdsMaxLog.  mode selects the fused
 // r2c epilogue / c2r prologue.  scale: multiply by 1/n (forward plans).
+// out_off (here and below): the results go to data + out_off complex elements — 0 = in place, otherwise a destination
+// that does not overlap the source (clfa_fft_exec_dev_oop); the source is only read
 hipError_t launch_fft_lds(int logn, bool fwd, int mode, bool scale, cpx *data, const FftTables &t,
-                          long batch, const DeviceInfo &di, hipStream_t s);
+                          long batch, const DeviceInfo &di, hipStream_t s, long out_off = 0);
 const char *name_fft_lds(int logn, bool fwd, int mode);
 // packed real size 65536 (n = 32768): two runs of the 16384-point machinery per transform, radix-2 step and pair
 // map in registers; t.half = the n = 16384 lane tables (kLane14Size), t.w2 = the plan's r2c table (n entries)
-hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
+hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s,
+                             long out_off = 0);
 // packed real size 32768 the same way on two 8192-point runs (two 512-lane workgroups per CU); t.half = the n = 8192
 // lane tables (kLane13Size), t.w2 = the plan's r2c table
-hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s);
+hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s,
+                            long out_off = 0);
 // complex n = 16384 as two 8192-point runs + a radix-2 step in registers; t.half = the n = 8192 lane tables
 // (kLane13Size) followed by W_16384^t, t < 512
 hipError_t launch_cfft_2x13(bool fwd, bool scale, cpx *data, const FftTables &t, long batch, const DeviceInfo &di,
-                            hipStream_t s);
+                            hipStream_t s, long out_off = 0);
 
 // four-step FFT, n = 2^logn in (2^kLdsMaxLog, 2^kMaxLog]; scratch = fourstep_grid() * n complex
 // (n = 65536 with more than a few transforms runs the resident kernel below and uses the first
 // kRes16SlotBytes * grid bytes of the scratch as its slots)
 int fourstep_grid(const DeviceInfo &di);
 hipError_t launch_fft_4step(int logn, bool fwd, bool scale, cpx *data, cpx *scratch, const FftTables &t, long batch,
-                            const DeviceInfo &di, hipStream_t s);
+                            const DeviceInfo &di, hipStream_t s, long out_off = 0);
 const char *name_fft_4step(int logn);
 int fourstep_split(int logn, int *logn1, int *logn2, int *loglo);
 // n = 65536, the whole intermediate resident on the CU (fft_resident.hip): one HBM pass, no scratch.
@@ -75,12 +79,13 @@ struct BigGeom {
 int big_split(int logn, BigGeom *g);
 // bigtabs: [half N1 | lo | hi]; sub: tables of the 2^logn2 row transform; scratch holds `batch`
 // transforms (batch <= 65535), scratch2 the row transform's own workspace (logn2 > kLdsMaxLog)
-hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *scratch, cpx *scratch2,
+// (out: where the last pass writes; data itself is only read)
+hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *out, cpx *scratch, cpx *scratch2,
                           const cpx *bigtabs, const FftTables &sub, long batch, const DeviceInfo &di, hipStream_t s);
 
 // stand-alone pack / unpack (reference kernels conv / iconv) for M above the LDS path
-hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
-hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s);
+hipError_t launch_r2c_pack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s, long out_off = 0);
+hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStream_t s, long out_off = 0);
 
 // arbitrary (non power-of-two) complex lengths, an extension: Bluestein's algorithm around two m-point
 // power-of-two transforms, m >= 2 n - 1 (fft_kernels.hip); n up to kBlueMaxN

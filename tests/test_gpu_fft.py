@@ -172,7 +172,7 @@ def test_cfft_batched_kernels_vs_reference_vectors(n):
 @pytest.mark.parametrize("n,batch", [(65536, 70), (65536, 300), (1024, 9), (16384, 70), (65536, 3)])
 def test_cfft_out_of_place(n, batch):
     """clfa_fft_exec_dev_oop (extension; the reference's device side is out of place too, cl_fft.cpp:138-151): the resident
-    kernel src -> dst for n = 65536 in batches, copy + in place for every other plan; the source stays untouched, and the
+    kernel src -> dst for n = 65536 in batches, every other kernel with its stores redirected; the source stays untouched, and the
     result is the reference's vector (golden input replicated) in every transform, forward and inverse"""
     import torch
     x = np.tile(util.lcg_complex(12345, n), (batch, 1))
@@ -209,7 +209,7 @@ def test_cfft_out_of_place_arguments():
 
 @pytest.mark.parametrize("size,batch", [(16384, 11), (65536, 40)])
 def test_rfft_out_of_place(size, batch):
-    """real plans through the out-of-place entry point (copy + in place): oracle parity, source untouched"""
+    """real plans through the out-of-place entry point: oracle parity, source untouched"""
     import torch
     r = (np.random.default_rng(size).random((batch, size), dtype=np.float32) * 2 - 1)
     src = torch.from_numpy(r.copy()).cuda()
@@ -218,6 +218,36 @@ def test_rfft_out_of_place(size, batch):
     torch.cuda.synchronize()
     assert np.array_equal(src.cpu().numpy(), r)
     assert_parity(dst.cpu().numpy().view(np.complex64), oracle.rfft_forward(r), what="rfft oop size %d" % size)
+
+
+@pytest.mark.parametrize("real,n,batch", [(False, 2, 1001), (False, 4, 77), (False, 64, 333), (False, 256, 17), (False, 4096, 5),
+                                          (False, 8192, 70), (False, 16384, 3), (False, 16384, 70), (False, 32768, 3),
+                                          (False, 32768, 70), (False, 65536, 3), (False, 1 << 17, 2), (False, 1 << 19, 1),
+                                          (False, 1 << 21, 1), (False, 1000, 9), (False, 44100, 2),
+                                          (True, 8, 1000), (True, 256, 130), (True, 512, 9), (True, 8192, 37), (True, 16384, 70),
+                                          (True, 32768, 3), (True, 32768, 70), (True, 65536, 3), (True, 65536, 40),
+                                          (True, 131072, 5), (True, 131072, 70), (True, 1 << 18, 2), (True, 1000, 7)])
+def test_out_of_place_equals_in_place(real, n, batch):
+    """Every route of the library through clfa_fft_exec_dev_oop (complex and packed real; one-, two- and three-pass
+    sizes; the few-transform routes; other lengths): forward and inverse, the destination holds bit for bit what the
+    in-place entry point produces, and the source is left untouched (routes of several passes must put their FIRST pass
+    into the destination)."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(n + batch)
+    shape = (batch, n) if real else (batch, n, 2)
+    for fwd in (True, False):
+        plan = (fa.Clrfft if real else fa.Clcfft)(0, n, fwd)
+        assert plan.get_error() == 0, plan.get_log()
+        src = torch.rand(shape, generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+        keep = src.clone()
+        dst = torch.full_like(src, float("nan"))
+        assert plan.exec_device_oop(src, dst, batch) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(src.view(torch.int32), keep.view(torch.int32)), "source modified (%s)" % plan.kernel_name()
+        assert plan.exec_device(src, batch) == 0
+        torch.cuda.synchronize()
+        assert not torch.isnan(dst).any()
+        assert torch.equal(src.view(torch.int32), dst.view(torch.int32)), "out of place differs from in place (%s)" % plan.kernel_name()
 
 
 @pytest.mark.parametrize("size,kernel", [(8192, "k_fft_lds"), (32768, "k_rfft_2x"), (65536, "k_rfft_2x"), (131072, None)])
