@@ -558,6 +558,199 @@ __device__ __forceinline__ void res_phase1_block(cpx (&v)[16], const ResLane &L,
   res_deposit<PROBE, LAST>(v, L, cb, K, slot);
 }
 
+
+// ---- packed real transforms of size 2 kN = 131072, forward (R2C): the reference's `conv` pair map (cl_fft.cpp:178-191)
+// inside phase 2, so that the transform still crosses HBM once.
+//
+// The map combines bins i and M - i (M = kN).  With i = 16 q + c + 256 (t + 16 e) (row block q, lane (c, t), register
+// e) the partner is 16 (15 - q) + (16 - c) + 256 (15 - t) + 4096 (15 - e): row block 15 - q, and — if that block is
+// worked through MIRRORED lane maps (the lane reads row (16 - c) mod 16 of the exchange and the first pass's output
+// 15 - t) — the same lane's register 15 - e.  So phase 2 runs the row blocks in pairs A = q, B = 15 - q (q = 0..7),
+// B mirrored, and the map is register-to-register in every lane with c != 0.  The lanes c = 0 (rows k1 = 16 rb) pair
+// one block further: A_q's with B_(q-1)'s (still in the same lane), which is why B's results stay parked for one
+// more block (in the AGPR row that block 15 has left free) and are completed there before their stores are issued;
+// rows k1 = 0 (in A_0) and k1 = 128 (in B_7) pair within themselves, across the 16 lanes c = 0, through 2 KiB of LDS.
+// Pair twiddles W_2M^i = W_2M^(16 q + c) * W_512^t * W_32^e: two lookups (the first 256 entries of the plan's w2 table
+// and every 256th) and compile-time constants.  The map's 1/2 rides on the 1/N of the table (r2c_pair_prescaled).
+constexpr int kTabPair = kTabSize;   // [W_2M^k, k < 256 | W_512^t, t < 16]
+constexpr int kTabSizeR = kTabSize + 272;
+constexpr int kParkAcc = 224;        // B' results parked in a[224:255] (keep row 15's registers, fetched first)
+constexpr int kSlotAcc = 192;        // the slot's row block lands in a[192:223] (keep row 14's, free after pair 1)
+
+template <int... I, class F> __device__ __forceinline__ void static_for_(std::integer_sequence<int, I...>, F &&f) { (f(ic<I>()), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_(std::make_integer_sequence<int, N>(), f); }
+
+template <int BASE> __device__ __forceinline__ void acc_fetch_flat(cpx (&v)[16]) {
+  static_for<16>([&](auto E) { v[decltype(E)::value] = mk(acc_read<BASE + 2 * decltype(E)::value>(), acc_read<BASE + 2 * decltype(E)::value + 1>()); });
+}
+template <int BASE> __device__ __forceinline__ void acc_park_flat(const cpx (&v)[16]) {
+  static_for<16>([&](auto E) { acc_write<BASE + 2 * decltype(E)::value>(v[decltype(E)::value].x); acc_write<BASE + 2 * decltype(E)::value + 1>(v[decltype(E)::value].y); });
+}
+struct HookStoreAcc {   // the parked B' block, out of a[kParkAcc ...]
+  __amdgpu_buffer_rsrc_t r;
+  int voff;
+  const int (&so)[16];
+  template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
+    if constexpr (K == 0)
+      asm volatile("s_nop 4\n\tbuffer_store_dwordx2 a[%c2:%c3], %0, %1, %4 offen" CLFA_STNT ::"v"(voff), "s"(r), "n"(kParkAcc + 2 * K), "n"(kParkAcc + 1 + 2 * K), "s"(so[K]) : "memory");
+    else
+      asm volatile("buffer_store_dwordx2 a[%c2:%c3], %0, %1, %4 offen" CLFA_STNT ::"v"(voff), "s"(r), "n"(kParkAcc + 2 * K), "n"(kParkAcc + 1 + 2 * K), "s"(so[K]) : "memory");
+  }
+};
+struct HookSlotAcc {   // the global slot's row block (all 16 columns) -> a[kSlotAcc ...]; sc1 as in HookSlot
+  __amdgpu_buffer_rsrc_t r;
+  int voff;
+  const int (&so)[16];
+  template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
+    int off;
+    asm volatile("s_lshr_b32 %0, %3, 4\n\ts_nop 4\n\tbuffer_load_dwordx2 a[%c4:%c5], %1, %2, %0 offen sc1"
+                 : "=&s"(off)
+                 : "v"(voff), "s"(r), "s"(so[K]), "n"(kSlotAcc + 2 * K), "n"(kSlotAcc + 1 + 2 * K)
+                 : "memory", "scc");
+  }
+};
+template <class A, class B> struct Hook2 {
+  A a;
+  B b;
+  template <int K> __device__ __forceinline__ void operator()(ic<K> k) const {
+    a(k);
+    b(k);
+  }
+};
+// all 16 stores of the landing registers at once (the last A' block of a transform)
+__device__ __forceinline__ void res_store_land(__amdgpu_buffer_rsrc_t r, int voff, const int (&so)[16]) {
+  const HookStore h{r, voff, so};
+  static_for<16>([&](auto Kc) { h(Kc); });
+}
+// a block's 16 stores out of compiler registers, with the pinned row offsets (the builtin of res_store() would make
+// hipcc hold a second copy of the 15 offsets in SGPRs, which this variant of the kernel does not have)
+__device__ __forceinline__ void res_store_so(const cpx (&v)[16], __amdgpu_buffer_rsrc_t r, int voff, const int (&so)[16]) {
+  asm volatile("s_nop 4" ::"s"(r) : "memory");   // (the descriptor's SGPRs may be fresh from SALU)
+#pragma unroll
+  for (int e = 0; e < 16; e++)
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" CLFA_STNT ::"v"(v[e]), "v"(voff), "s"(r), "s"(so[e]) : "memory");
+}
+// halves of the landing registers <-> compiler registers
+template <int H> __device__ __forceinline__ void res_land_fetch8(cpx (&a)[8]) {
+  if constexpr (H == 0)
+    asm volatile("v_mov_b64 %0, v[224:225]\n\tv_mov_b64 %1, v[226:227]\n\tv_mov_b64 %2, v[228:229]\n\tv_mov_b64 %3, v[230:231]\n\t"
+                 "v_mov_b64 %4, v[232:233]\n\tv_mov_b64 %5, v[234:235]\n\tv_mov_b64 %6, v[236:237]\n\tv_mov_b64 %7, v[238:239]"
+                 : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]));
+  else
+    asm volatile("v_mov_b64 %0, v[240:241]\n\tv_mov_b64 %1, v[242:243]\n\tv_mov_b64 %2, v[244:245]\n\tv_mov_b64 %3, v[246:247]\n\t"
+                 "v_mov_b64 %4, v[248:249]\n\tv_mov_b64 %5, v[250:251]\n\tv_mov_b64 %6, v[252:253]\n\tv_mov_b64 %7, v[254:255]"
+                 : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]));
+}
+template <int H> __device__ __forceinline__ void res_stage8(const cpx (&a)[8]) {
+  if constexpr (H == 0)
+    asm volatile("v_mov_b64 v[224:225], %0\n\tv_mov_b64 v[226:227], %1\n\tv_mov_b64 v[228:229], %2\n\tv_mov_b64 v[230:231], %3\n\t"
+                 "v_mov_b64 v[232:233], %4\n\tv_mov_b64 v[234:235], %5\n\tv_mov_b64 v[236:237], %6\n\tv_mov_b64 v[238:239], %7"
+                 ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+  else
+    asm volatile("v_mov_b64 v[240:241], %0\n\tv_mov_b64 v[242:243], %1\n\tv_mov_b64 v[244:245], %2\n\tv_mov_b64 v[246:247], %3\n\t"
+                 "v_mov_b64 v[248:249], %4\n\tv_mov_b64 v[250:251], %5\n\tv_mov_b64 v[252:253], %6\n\tv_mov_b64 v[254:255], %7"
+                 ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+}
+// W_2M^i of the lane's register e: base * W_32^e
+template <int E> __device__ __forceinline__ cpx pair_tw_e(cpx base) {
+  if constexpr (E == 0) return base;
+  else return ctw<true>(base, kC32[E], kS32[E]);
+}
+// r2c_pair_prescaled (fft_device.hpp) in six packed instructions: the conjugations and the rotation by i ride on the
+// operand modifiers.  One wave per SIMD pays for every instruction in full, so the map is written out here.
+__device__ __forceinline__ void r2c_pair6(cpx a, cpx b, cpx w, cpx &oi, cpx &oj) {
+  cpx e, r, x, y;
+  asm("v_pk_add_f32 %0, %4, %5 neg_hi:[0,1]\n\t"                                 // e = a + conj(b)
+      "v_pk_add_f32 %1, %4, %5 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"    // r = i (conj(b) - a) = (a.y + b.y, b.x - a.x)
+      "v_pk_mul_f32 %2, %6, %1 op_sel_hi:[0,1]\n\t"                              // x = w r
+      "v_pk_fma_f32 %2, %6, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_add_f32 %3, %0, %2 neg_lo:[0,1] neg_hi:[1,0]\n\t"                    // y = conj(e - x)
+      "v_pk_add_f32 %2, %0, %2"                                                   // x = e + x
+      : "=&v"(e), "=&v"(r), "=&v"(x), "=&v"(y)
+      : "v"(a), "v"(b), "v"(w));
+  oi = x;
+  oj = y;
+}
+// lanes c != 0, end of pair q: the A block (raw, in the landing registers) against the B block (raw, in v);
+// A' back to the landing registers, B' left in v
+__device__ __forceinline__ void res_pair_map(cpx (&v)[16], cpx base) {
+  {
+    cpx a[8];
+    res_land_fetch8<0>(a);
+    static_for<8>([&](auto E) {
+      constexpr int e = decltype(E)::value;
+      r2c_pair6(a[e], v[15 - e], pair_tw_e<e>(base), a[e], v[15 - e]);
+      // results materialised here: hipcc otherwise sinks their last additions to the end of the (divergent) block, holds
+      // two temporaries per value until then and spills — into AGPRs, which are this kernel's own
+      asm volatile("" : "+v"(a[e]), "+v"(v[15 - e]));
+      if (e & 1) __builtin_amdgcn_sched_barrier(0);
+    });
+    res_stage8<0>(a);
+  }
+  {
+    cpx a[8];
+    res_land_fetch8<1>(a);
+    static_for<8>([&](auto E) {
+      constexpr int e = 8 + decltype(E)::value;
+      r2c_pair6(a[e - 8], v[15 - e], pair_tw_e<e>(base), a[e - 8], v[15 - e]);
+      asm volatile("" : "+v"(a[e - 8]), "+v"(v[15 - e]));
+      if (e & 1) __builtin_amdgcn_sched_barrier(0);
+    });
+    res_stage8<1>(a);
+  }
+}
+// lanes c = 0, pair q >= 1, after the A block: its rows k1 = 16 q pair with the previous B block's k1 = 16 (16 - q),
+// parked raw in a[kParkAcc ...] of these lanes; both are finished here
+__device__ __forceinline__ void res_pair_patch_c0(cpx (&v)[16], cpx base) {
+  static_for<16>([&](auto E) {
+    constexpr int e = decltype(E)::value, pe = kParkAcc + 2 * (15 - e);
+    const cpx bq = mk(acc_read<pe>(), acc_read<pe + 1>());
+    cpx oi, oj;
+    r2c_pair6(v[e], bq, pair_tw_e<e>(base), oi, oj);
+    v[e] = oi;
+    asm volatile("" : "+v"(v[e]));
+    acc_write<pe>(oj.x);
+    acc_write<pe + 1>(oj.y);
+    if (e & 1) __builtin_amdgcn_sched_barrier(0);
+  });
+}
+// lanes c = 0 of a block whose row pairs within itself (k1 = 0: natural lanes, k2 = t + 16 e; k1 = 128: mirrored
+// lanes, k2 = (15 - t) + 16 e): the partners are in other lanes c = 0 -> through s_c0[t][e].  Every lane computes
+// its own 16 results (each pair twice, by both of its lanes).  ROW0 has the reference's two exceptions: bin 0 packs
+// DC / Nyquist, bin M/2 is left as the complex transform made it (cl_fft.cpp:178-191 starts at i = 1 and never
+// reaches M/2).  Called by all lanes (barrier inside).
+template <bool ROW0> __device__ __forceinline__ void res_pair_self_row(cpx (&v)[16], int c, int t, cpx base, cpx *s_c0) {
+  if (c == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) s_c0[t * 16 + e] = v[e];
+  }
+  __syncthreads();
+  if (c == 0) {
+    static_for<16>([&](auto E) {
+      constexpr int e = decltype(E)::value;
+      int idx;
+      if constexpr (ROW0) {
+        const int k2 = (256 - (t + 16 * e)) & 255;
+        idx = (k2 & 15) * 16 + (k2 >> 4);
+      } else {
+        idx = (15 - t) * 16 + (15 - e);
+      }
+      const cpx ci = v[e], zp = s_c0[idx];
+      cpx oi, oj;
+      r2c_pair6(ci, zp, pair_tw_e<e>(base), oi, oj);
+      if constexpr (ROW0 && e == 0) {
+        if (t == 0) oi = mk(ci.x + ci.y, ci.x - ci.y);
+      }
+      if constexpr (ROW0 && e == 8) {
+        if (t == 0) oi = cscale(ci, 2.0f);
+      }
+      v[e] = oi;
+      asm volatile("" : "+v"(v[e]));
+      if (e & 1) __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+}
+
 }  // namespace
 
 #ifdef CLFA_RES16_PROBE
@@ -578,22 +771,32 @@ __device__ __forceinline__ void res_probe_grid_sync(unsigned long long *dbg, uns
 #endif
 
 // slots: one 32 KiB slot per workgroup (the single row block that does not fit the CU)
-template <bool FWD, bool SCALE, int PROBE = 0>
+// R2C: packed real transforms of size 2 kN, forward — the same transform with the reference's pair map inside phase 2
+// (above); w2_g = the plan's pair twiddles W_2M^i (cl_fft.cpp:233-238), M entries
+template <bool FWD, bool SCALE, int PROBE = 0, bool R2C = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_fft_res16(const cpx *data, cpx *out, cpx *__restrict__ slots,
                                                    const cpx *__restrict__ tabs_g, long batch,
-                                                   unsigned long long *__restrict__ dbg = nullptr) {
+                                                   unsigned long long *__restrict__ dbg = nullptr,
+                                                   const cpx *__restrict__ w2_g = nullptr) {
 #ifndef CLFA_RES16_PROBE
   static_assert(PROBE == 0, "the timing experiments exist only in tools/res16_probe.hip (CLFA_RES16_PROBE)");
 #endif
-  __shared__ __attribute__((aligned(16))) cpx s_tab[kTabSize];
+  static_assert(!R2C || (FWD && SCALE && PROBE == 0), "the fused pair map is the forward one");
+  __shared__ __attribute__((aligned(16))) cpx s_tab[R2C ? kTabSizeR : kTabSize];
   __shared__ __attribute__((aligned(16))) cpx s_x[kXSize];
   __shared__ __attribute__((aligned(16))) char s_spill[256 * kSpillStride];
+  __shared__ __attribute__((aligned(16))) cpx s_c0[R2C ? 256 : 1];
   acc_claim_all();
   const int tid = threadIdx.x;
   for (int i = tid; i < kTabSize; i += 256) {
     cpx w = tabs_g[i];
-    if (SCALE && i >= kTabLo && i < kTabHi) w = cscale(w, 1.0f / (float)kN);   // exact: a power of two
+    // exact: powers of two (R2C: the pair map's 1/2 as well)
+    if (SCALE && i >= kTabLo && i < kTabHi) w = cscale(w, R2C ? 0.5f / (float)kN : 1.0f / (float)kN);
     s_tab[i] = w;
+  }
+  if constexpr (R2C) {
+    s_tab[kTabPair + tid] = w2_g[tid];
+    if (tid < 16) s_tab[kTabPair + 256 + tid] = w2_g[256 * tid];
   }
   // The lane's addresses are recomputed from an opaque copy of the lane index wherever a block
   // starts: as loop invariants they would cost ~13 VGPRs for the whole kernel, which hipcc then
@@ -612,6 +815,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     L.tw_row = s_tab + kTabTw + 16 * L.t;
     L.spill = s_spill + l * kSpillStride;
     L.slot_off = l * 8;
+    return L;
+  };
+  // R2C, the B block of a pair: row (16 - c) mod 16 of the exchange, first-pass output 15 - t (and the stores follow)
+  [[maybe_unused]] auto lane_m = [&]() {
+    ResLane L = lane();
+    const int cm = (16 - L.c) & 15, tm = 15 - L.t;
+    L.voff = tm * 2048 + cm * 8;
+    L.xb_r = s_x + cm * kXB + tm;
+    L.tw_row = s_tab + kTabTw + 16 * tm;
     return L;
   };
   const int rot = (PROBE & kProbeRotate) ? (int)(blockIdx.x & 15) : 0;   // probe only: 0 in the library
@@ -693,7 +905,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     res_phase1_block<FWD, PROBE, kZone0, kZone1, true>(v, lane(), x, 12, rot, so, K, slot, s_tab, s_x);
     res_phase1_block<FWD, PROBE, -1, -1, true>(v, lane(), x, 13, rot, so, K, slot, s_tab, s_x);
     res_phase1_block<FWD, PROBE, kZone1, -1, false>(v, lane(), x, 14, rot, so, K, slot, s_tab, s_x);
-    res_phase1_block<FWD, PROBE, -1, -1, false, 0, true>(v, lane(), x, 15, rot, so, K, slot, s_tab, s_x);
+    if constexpr (R2C) res_phase1_block<FWD, PROBE, -1, -1, false, 0, false>(v, lane(), x, 15, rot, so, K, slot, s_tab, s_x);
+    else res_phase1_block<FWD, PROBE, -1, -1, false, 0, true>(v, lane(), x, 15, rot, so, K, slot, s_tab, s_x);
 #ifdef CLFA_RES16_PROBE
     if constexpr (PROBE & kProbeStamps) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -719,6 +932,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     bn = bmap(kk + 1 < per ? kk + 1 : kk);
 #endif
     const cpx *xn = data + bn * (long)kN;
+    if constexpr (R2C) {
+      // ---- phase 2 of the packed real transform: pairs of row blocks (A = q natural, B = 15 - q mirrored), see above
+#pragma unroll 1
+      for (int q = 0; q < 8; q++) {
+        // stores into a zero-length buffer are dropped: pair 0 has nothing to store yet
+        const unsigned live = q ? 0x7fffffffu : 0u;
+        cpx base;
+        {
+          const ResLane L = lane();
+          switch (q) {
+            case 0: res_fetch_static<0>(v, L, K); break;
+            case 1: res_fetch_static<1>(v, L, K); break;
+            case 2: res_fetch_static<2>(v, L, K); break;
+            case 3:   // the slot's block: loaded along block A_2; the 16 stores of block B_2 are younger
+              res_wait_vm<16>();
+              acc_fetch_flat<kSlotAcc>(v);
+              break;
+            case 4: res_fetch_static<4>(v, L, K); break;
+            case 5: res_fetch_static<5>(v, L, K); break;
+            case 6: res_fetch_static<6>(v, L, K); break;
+            default: res_fetch_static<7>(v, L, K); break;
+          }
+          // ... with the stores of A'_(q-1) (landing registers) riding along
+          const __amdgpu_buffer_rsrc_t ra =
+              __builtin_amdgcn_make_buffer_rsrc(y + (q - 1) * 16, 0, live, 0x00020000);
+          if (q == 2) res_row_block<FWD, PROBE>(v, L, Hook2<HookStore, HookSlotAcc>{HookStore{ra, L.voff, so}, HookSlotAcc{slot, L.slot_off, so}});
+          else res_row_block<FWD, PROBE>(v, L, HookStore{ra, L.voff, so});
+          base = cmul(s_tab[kTabPair + 16 * q + L.c], s_tab[kTabPair + 256 + L.t]);
+          if (q == 0) {
+            res_pair_self_row<true>(v, L.c, L.t, base, s_c0);
+          } else if (L.c == 0) {
+            res_pair_patch_c0(v, base);
+          }
+          res_stage(v);   // A_q: raw in the lanes c != 0, finished in the lanes c = 0
+        }
+        {
+          const ResLane L = lane_m();
+          switch (q) {
+            case 0: res_fetch_static<15>(v, L, K); break;
+            case 1: res_fetch_static<14>(v, L, K); break;
+            case 2: res_fetch_static<13>(v, L, K); break;
+            case 3: res_fetch_static<12>(v, L, K); break;
+            case 4: res_fetch_static<11>(v, L, K); break;
+            case 5: res_fetch_static<10>(v, L, K); break;
+            case 6: res_fetch_static<9>(v, L, K); break;
+            default: res_fetch_static<8>(v, L, K); break;
+          }
+          // ... with the stores of B'_(q-1) (parked in the accumulation registers, finished by the patch above)
+          const __amdgpu_buffer_rsrc_t rb =
+              __builtin_amdgcn_make_buffer_rsrc(y + (16 - q) * 16, 0, live, 0x00020000);
+          res_row_block<FWD, PROBE>(v, L, HookStoreAcc{rb, L.voff, so});
+          if (L.c != 0) res_pair_map(v, base);
+          if (q == 7) {
+            const cpx bm = cmul(s_tab[kTabPair + 128], s_tab[kTabPair + 256 + 15 - L.t]);
+            res_pair_self_row<false>(v, L.c, L.t, bm, s_c0);
+          } else {
+            acc_park_flat<kParkAcc>(v);   // B'_q (its lanes c = 0 still raw)
+          }
+        }
+      }
+      {
+        const ResLane L = lane(), Lm = lane_m();
+        res_store_land(res_rsrc(y + 7 * 16), L.voff, so);
+        res_store_so(v, res_rsrc(y + 8 * 16), Lm.voff, so);
+        // the next transform's blocks 0 and 1
+        res_load_acc<kZone0>(xn, L.voff);
+        res_load_land(xn + 16, L.voff);
+      }
+    } else {
     {
       const ResLane L = lane();
       if constexpr (!(PROBE & kProbeNoSlot)) res_wait_vm<0>();
@@ -761,6 +1043,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       // the next transform's block 1 -> landing registers (after this block's parked stores have been issued)
       if constexpr (!(PROBE & kProbeNoLoad)) res_load_land(xn + ((1 + rot) & 15) * 16, L.voff);
     }
+    }   // !R2C
 #ifdef CLFA_RES16_PROBE
     if constexpr (PROBE & kProbePack) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -815,6 +1098,15 @@ hipError_t launch_fft_res16(bool fwd, bool scale, const cpx *data, cpx *out, cpx
   else if (fwd) hipLaunchKernelGGL((k_fft_res16<true, false>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch);
   else if (!scale) hipLaunchKernelGGL((k_fft_res16<false, false>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_rfft_res16(const cpx *data, cpx *out, cpx *slots, const cpx *tabs, const cpx *w2, long batch,
+                             const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  const int grid = (int)(batch < di.num_cus ? batch : di.num_cus);
+  hipLaunchKernelGGL((k_fft_res16<true, true, 0, true>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch,
+                     (unsigned long long *)nullptr, w2);
   return hipGetLastError();
 }
 

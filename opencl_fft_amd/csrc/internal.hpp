@@ -70,6 +70,10 @@ constexpr size_t kRes16SlotBytes = 32768;
 // out == data: in place (what every plan does); out != data: out of place (measured in tools/res16_probe.hip)
 hipError_t launch_fft_res16(bool fwd, bool scale, const cpx *data, cpx *out, cpx *slots, const cpx *tabs, long batch,
                             const DeviceInfo &di, hipStream_t s);
+// packed real transforms of size 131072, forward: the same kernel with the reference's pair map inside its second
+// phase (w2 = the plan's pair twiddles, 65536 entries) — one HBM pass instead of the transform + k_r2c_pack
+hipError_t launch_rfft_res16(const cpx *data, cpx *out, cpx *slots, const cpx *tabs, const cpx *w2, long batch,
+                             const DeviceInfo &di, hipStream_t s);
 // n = 2^17 .. 2^kBigMaxLog (extension: the reference overflows above 65536): columns + rows + transpose
 constexpr int kBigMaxLog = 24;
 struct BigGeom {
