@@ -630,27 +630,6 @@ __device__ __forceinline__ void res_store_so(const cpx (&v)[16], __amdgpu_buffer
   for (int e = 0; e < 16; e++)
     asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" CLFA_STNT ::"v"(v[e]), "v"(voff), "s"(r), "s"(so[e]) : "memory");
 }
-// halves of the landing registers <-> compiler registers
-template <int H> __device__ __forceinline__ void res_land_fetch8(cpx (&a)[8]) {
-  if constexpr (H == 0)
-    asm volatile("v_mov_b64 %0, v[224:225]\n\tv_mov_b64 %1, v[226:227]\n\tv_mov_b64 %2, v[228:229]\n\tv_mov_b64 %3, v[230:231]\n\t"
-                 "v_mov_b64 %4, v[232:233]\n\tv_mov_b64 %5, v[234:235]\n\tv_mov_b64 %6, v[236:237]\n\tv_mov_b64 %7, v[238:239]"
-                 : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]));
-  else
-    asm volatile("v_mov_b64 %0, v[240:241]\n\tv_mov_b64 %1, v[242:243]\n\tv_mov_b64 %2, v[244:245]\n\tv_mov_b64 %3, v[246:247]\n\t"
-                 "v_mov_b64 %4, v[248:249]\n\tv_mov_b64 %5, v[250:251]\n\tv_mov_b64 %6, v[252:253]\n\tv_mov_b64 %7, v[254:255]"
-                 : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]));
-}
-template <int H> __device__ __forceinline__ void res_stage8(const cpx (&a)[8]) {
-  if constexpr (H == 0)
-    asm volatile("v_mov_b64 v[224:225], %0\n\tv_mov_b64 v[226:227], %1\n\tv_mov_b64 v[228:229], %2\n\tv_mov_b64 v[230:231], %3\n\t"
-                 "v_mov_b64 v[232:233], %4\n\tv_mov_b64 v[234:235], %5\n\tv_mov_b64 v[236:237], %6\n\tv_mov_b64 v[238:239], %7"
-                 ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
-  else
-    asm volatile("v_mov_b64 v[240:241], %0\n\tv_mov_b64 v[242:243], %1\n\tv_mov_b64 v[244:245], %2\n\tv_mov_b64 v[246:247], %3\n\t"
-                 "v_mov_b64 v[248:249], %4\n\tv_mov_b64 v[250:251], %5\n\tv_mov_b64 v[252:253], %6\n\tv_mov_b64 v[254:255], %7"
-                 ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
-}
 // W_2M^i of the lane's register e: base * W_32^e
 template <int E> __device__ __forceinline__ cpx pair_tw_e(cpx base) {
   if constexpr (E == 0) return base;
@@ -671,33 +650,28 @@ __device__ __forceinline__ void r2c_pair6(cpx a, cpx b, cpx w, cpx &oi, cpx &oj)
   oi = x;
   oj = y;
 }
-// lanes c != 0, end of pair q: the A block (raw, in the landing registers) against the B block (raw, in v);
-// A' back to the landing registers, B' left in v
+// ... with the A value in (and the result back into) the landing register pair of register E: no moves
+template <int E> __device__ __forceinline__ void r2c_pair6_land(cpx &b, cpx w) {
+  cpx e, r, y;
+  asm volatile("v_pk_add_f32 %0, v[%c5:%c6], %3 neg_hi:[0,1]\n\t"
+               "v_pk_add_f32 %1, v[%c5:%c6], %3 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+               "v_pk_mul_f32 v[%c5:%c6], %4, %1 op_sel_hi:[0,1]\n\t"
+               "v_pk_fma_f32 v[%c5:%c6], %4, %1, v[%c5:%c6] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+               "v_pk_add_f32 %2, %0, v[%c5:%c6] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+               "v_pk_add_f32 v[%c5:%c6], %0, v[%c5:%c6]"
+               : "=&v"(e), "=&v"(r), "=&v"(y)
+               : "v"(b), "v"(w), "n"(224 + 2 * E), "n"(225 + 2 * E));
+  b = y;
+}
+// lanes c != 0, end of pair q: the A block (raw, in the landing registers) against the B block (raw, in v); A' stays
+// in the landing registers, B' in v
 __device__ __forceinline__ void res_pair_map(cpx (&v)[16], cpx base) {
-  {
-    cpx a[8];
-    res_land_fetch8<0>(a);
-    static_for<8>([&](auto E) {
-      constexpr int e = decltype(E)::value;
-      r2c_pair6(a[e], v[15 - e], pair_tw_e<e>(base), a[e], v[15 - e]);
-      // results materialised here: hipcc otherwise sinks their last additions to the end of the (divergent) block, holds
-      // two temporaries per value until then and spills — into AGPRs, which are this kernel's own
-      asm volatile("" : "+v"(a[e]), "+v"(v[15 - e]));
-      if (e & 1) __builtin_amdgcn_sched_barrier(0);
-    });
-    res_stage8<0>(a);
-  }
-  {
-    cpx a[8];
-    res_land_fetch8<1>(a);
-    static_for<8>([&](auto E) {
-      constexpr int e = 8 + decltype(E)::value;
-      r2c_pair6(a[e - 8], v[15 - e], pair_tw_e<e>(base), a[e - 8], v[15 - e]);
-      asm volatile("" : "+v"(a[e - 8]), "+v"(v[15 - e]));
-      if (e & 1) __builtin_amdgcn_sched_barrier(0);
-    });
-    res_stage8<1>(a);
-  }
+  static_for<16>([&](auto E) {
+    constexpr int e = decltype(E)::value;
+    r2c_pair6_land<e>(v[15 - e], pair_tw_e<e>(base));
+    // (every two pairs a fence: hipcc otherwise piles up all 16 twiddles and spills — into AGPRs, this kernel's own)
+    if (e & 1) __builtin_amdgcn_sched_barrier(0);
+  });
 }
 // lanes c = 0, pair q >= 1, after the A block: its rows k1 = 16 q pair with the previous B block's k1 = 16 (16 - q),
 // parked raw in a[kParkAcc ...] of these lanes; both are finished here
