@@ -278,6 +278,39 @@ def test_rfft_batched_kernels_vs_reference_vectors(size, kernel):
         assert_parity(util.decimate(arb[b]), ref, what="size=%d invarb %d" % (size, b))
 
 
+@pytest.mark.parametrize("batch", [65, 257, 300, 777])
+def test_rfft131072_forward_one_pass_ragged(batch):
+    """Clrfft forward (cl_fft.cpp:272-282) of size 131072 with more than CUs / 4 transforms: ONE launch — the resident
+    65536-point kernel with the reference's `conv` pair map (cl_fft.cpp:178-191) inside its second phase.  Ragged batches
+    (not multiples of the grid, one workgroup with one transform more than its neighbour); transforms picked across the
+    batch against the oracle, with the map's special bins (0: DC / Nyquist packed, M/2: left as the complex transform made
+    it) and the rows that pair across lanes (k1 = 0, 128) checked by name; out of place bit for bit the same."""
+    import torch
+    size, m = 131072, 65536
+    rng = np.random.default_rng(batch)
+    r = (rng.random((batch, size), dtype=np.float32) * 2 - 1).astype(np.float32)
+    f = fa.Clrfft(0, size, True)
+    assert f.get_error() == 0 and f.kernel_name() == "k_fft_res16"
+    d = torch.from_numpy(r.copy()).cuda()
+    assert f.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().view(np.complex64).reshape(batch, m)
+    pick = sorted(set([0, 1, batch // 2, 255 % batch, 256 % batch, batch - 2, batch - 1]))
+    want = oracle.rfft_forward(r[pick])
+    assert_parity(got[pick], want, what="rfft 131072 batch %d" % batch)
+    scale = np.abs(want).max()
+    for name, idx in (("bin 0", [0]), ("bin M/2", [m // 2]), ("row k1 = 0", np.arange(0, m, 256)), ("row k1 = 128", np.arange(128, m, 256)),
+                      ("lanes c = 0", np.arange(0, m, 16))):
+        err = np.abs(got[pick][:, idx] - want[:, idx]).max() / scale
+        assert err < 1e-6, (name, err)
+    src = torch.from_numpy(r).cuda()
+    dst = torch.full_like(src, float("nan"))
+    assert f.exec_device_oop(src, dst, batch) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst.view(torch.int32), d.view(torch.int32))
+    assert np.array_equal(src.cpu().numpy(), r)
+
+
 @pytest.mark.parametrize("n,batch", [(16384, 70), (16384, 300), (32768, 70), (32768, 300), (65536, 70), (65536, 300)])
 def test_cfft_persistent_kernel_ragged(n, batch):
     """the persistent four-step kernel (intermediate in LDS + registers) with batch counts that are
