@@ -269,7 +269,7 @@ struct clfa_fft {
   bool rlds15 = false;   // packed real size 65536: k_rfft_2x<14> (two 16384-point runs per transform, one HBM pass)
   bool c2x13 = false;    // complex n = 16384: k_cfft_2x<13> (two 8192-point runs per transform, two workgroups per CU)
   bool r2x13 = false;    // packed real size 32768: k_rfft_2x<13> (the same, with the pair maps in registers)
-  bool r16 = false;      // packed real size 131072, forward: k_fft_res16 with the pair map inside (one HBM pass)
+  bool r16 = false;      // packed real size 131072: k_fft_res16 with the pair map inside (one HBM pass), either direction
   DevBuf half2;          // ... the tables of the last two: the n = 8192 lane tables + W_16384^t, t < 512
   long spread_below = 0; // real sizes 32768 / 65536: batches up to this run the four-step pair + pack kernel instead
   // any other length (extension): Bluestein around two power-of-two plans of length blue_m
@@ -522,7 +522,7 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
   p->rlds15 = real && p->logn == 15;
   p->r2x13 = real && p->logn == 14;
   p->c2x13 = !real && p->logn == 14;
-  p->r16 = real && fwd && p->logn == 16;
+  p->r16 = real && p->logn == 16;
   // The fused real kernels put one workgroup on a transform (13-23 us for a single one); a few transforms are
   // faster spread over the column / row blocks of the four-step pair plus the pack kernel (11 us): real plans of
   // these two sizes carry both sets of tables and exec picks by batch (p->spread_below).
@@ -710,7 +710,8 @@ static int fft_exec(clfa_fft *p, cpx *d, long off, long batch, hipStream_t s) {
     return CLFA_SUCCESS;
   }
   if (p->r16 && batch * 4 > fourstep_grid(p->di)) {   // (fewer transforms: spread over the column / row kernels + pack)
-    HIP_TRY(launch_rfft_res16(d, o, (cpx *)p->scratch.p, p->tabs.res16, p->tabs.w2, batch, p->di, s));
+    if (p->fwd) HIP_TRY(launch_rfft_res16(d, o, (cpx *)p->scratch.p, p->tabs.res16, p->tabs.w2, batch, p->di, s));
+    else HIP_TRY(launch_crfft_res16(d, o, (cpx *)p->scratch.p, p->tabs.res16, p->tabs.w2, batch, p->di, s));
     return CLFA_SUCCESS;
   }
   // a complex transform, with the reference's pack / unpack as a pass of its own for the packed real sizes that have no

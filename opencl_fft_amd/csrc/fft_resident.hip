@@ -109,14 +109,19 @@ __device__ __forceinline__ void acc_claim_all() {
 // They fall free in the order Z0 (block 12 taken out), Z1 (block 14 taken out), so the keep matrix's
 // columns 12..15 are stored swapped: logical column c lives in physical column acc_col(c).
 constexpr int kZone0 = 14, kZone1 = 12;
-constexpr int acc_col(int c) { return c < 12 ? c : c ^ 2; }
+// INV (the packed real inverse kernel, whose phase 1 takes the column blocks in the order 7, 8, 6, 9, ... 0, 15): the
+// zones are the columns of the blocks deposited last there — Z0 = blocks 0, 15, Z1 = blocks 1, 14
+template <bool INV = false> constexpr int acc_col(int c) {
+  if (INV) return c == 0 ? 14 : c == 15 ? 15 : c == 1 ? 12 : c == 14 ? 13 : c - 2;
+  return c < 12 ? c : c ^ 2;
+}
 // column block CB: element e = 8 + J of the lane's results goes to a[32 J + 2 acc_col(CB)]
-template <int CB, int... J> __device__ __forceinline__ void acc_deposit(const cpx (&o)[16], std::integer_sequence<int, J...>) {
-  ((acc_write<32 * J + 2 * acc_col(CB)>(o[kAgprFirst + J].x), acc_write<32 * J + 2 * acc_col(CB) + 1>(o[kAgprFirst + J].y)), ...);
+template <int CB, bool INV, int... J> __device__ __forceinline__ void acc_deposit(const cpx (&o)[16], std::integer_sequence<int, J...>) {
+  ((acc_write<32 * J + 2 * acc_col<INV>(CB)>(o[kAgprFirst + J].x), acc_write<32 * J + 2 * acc_col<INV>(CB) + 1>(o[kAgprFirst + J].y)), ...);
 }
 // row block 8 + RB: a[32 RB + 2 acc_col(e)] -> v[e]
-template <int RB, int... E> __device__ __forceinline__ void acc_fetch(cpx (&v)[16], std::integer_sequence<int, E...>) {
-  ((v[E].x = acc_read<32 * RB + 2 * acc_col(E)>(), v[E].y = acc_read<32 * RB + 2 * acc_col(E) + 1>()), ...);
+template <int RB, bool INV, int... E> __device__ __forceinline__ void acc_fetch(cpx (&v)[16], std::integer_sequence<int, E...>) {
+  ((v[E].x = acc_read<32 * RB + 2 * acc_col<INV>(E)>(), v[E].y = acc_read<32 * RB + 2 * acc_col<INV>(E) + 1>()), ...);
 }
 
 // ---- global accesses ----------------------------------------------------------------------------
@@ -236,7 +241,9 @@ __device__ __forceinline__ void res_land_fetch(cpx (&v)[16]) {
 }
 // waits for the asm loads: N = the asm loads issued after the awaited ones
 template <int N> __device__ __forceinline__ void res_wait_vm() {
-  static_assert(N == 0 || N == 16 || N == 32 || N == 48, "");
+  static_assert(N == 0 || N == 1 || N == 2 || N == 16 || N == 32 || N == 48, "");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   if constexpr (N == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -454,7 +461,7 @@ __device__ __forceinline__ void res_col_block(cpx (&v)[16], const ResLane &L, in
 // o[e] -> keep[e][cb]
 // LAST (column block 15): the slot's element goes straight to its landing register (the rest of that row
 // block is on its way there, HookSlot)
-template <int PROBE = 0, bool LAST = false>
+template <int PROBE = 0, bool LAST = false, bool INV = false>
 __device__ __forceinline__ void res_deposit(const cpx (&o)[16], const ResLane &L, int cb, f32x32 (&K)[kVgprBlk],
                                             __amdgpu_buffer_rsrc_t slot) {
   {
@@ -473,16 +480,16 @@ __device__ __forceinline__ void res_deposit(const cpx (&o)[16], const ResLane &L
   }
   using S8 = std::make_integer_sequence<int, kAgprBlk>;
   switch (cb) {
-#define CLFA_C(c) case c: acc_deposit<c>(o, S8()); break;
+#define CLFA_C(c) case c: acc_deposit<c, INV>(o, S8()); break;
     CLFA_C(0) CLFA_C(1) CLFA_C(2) CLFA_C(3) CLFA_C(4) CLFA_C(5) CLFA_C(6) CLFA_C(7)
     CLFA_C(8) CLFA_C(9) CLFA_C(10) CLFA_C(11) CLFA_C(12) CLFA_C(13) CLFA_C(14)
 #undef CLFA_C
-    default: acc_deposit<15>(o, S8()); break;
+    default: acc_deposit<15, INV>(o, S8()); break;
   }
 }
 
 // keep[rb][e] -> v[e]
-template <int RB> __device__ __forceinline__ void res_fetch_static(cpx (&v)[16], const ResLane &L, const f32x32 (&K)[kVgprBlk]) {
+template <int RB, bool INV = false> __device__ __forceinline__ void res_fetch_static(cpx (&v)[16], const ResLane &L, const f32x32 (&K)[kVgprBlk]) {
   if constexpr (RB < kLdsBlk) {
     const f4 *pf = reinterpret_cast<const f4 *>(L.spill + RB * 128);
 #pragma unroll
@@ -497,7 +504,7 @@ template <int RB> __device__ __forceinline__ void res_fetch_static(cpx (&v)[16],
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = mk(K[RB - kVgprFirst][2 * e], K[RB - kVgprFirst][2 * e + 1]);
   } else {
-    acc_fetch<RB - kAgprFirst>(v, std::make_integer_sequence<int, 16>());
+    acc_fetch<RB - kAgprFirst, INV>(v, std::make_integer_sequence<int, 16>());
   }
 }
 // ---- phase 2: one row block ---------------------------------------------------------------------
@@ -572,6 +579,10 @@ __device__ __forceinline__ void res_phase1_block(cpx (&v)[16], const ResLane &L,
 // rows k1 = 0 (in A_0) and k1 = 128 (in B_7) pair within themselves, across the 16 lanes c = 0, through 2 KiB of LDS.
 // Pair twiddles W_2M^i = W_2M^(16 q + c) * W_512^t * W_32^e: two lookups (the first 256 entries of the plan's w2 table
 // and every 256th) and compile-time constants.  The map's 1/2 rides on the 1/N of the table (r2c_pair_prescaled).
+#ifndef CLFA_C2R_WAIT
+#define CLFA_C2R_WAIT 1
+#endif
+constexpr bool kC2rWait = CLFA_C2R_WAIT;   // 0 (dev builds): every wait of the inverse kernel's phase 1 is vmcnt(0)
 constexpr int kTabPair = kTabSize;   // [W_2M^k, k < 256 | W_512^t, t < 16]
 constexpr int kTabSizeR = kTabSize + 272;
 constexpr int kParkAcc = 224;        // B' results parked in a[224:255] (keep row 15's registers, fetched first)
@@ -631,9 +642,9 @@ __device__ __forceinline__ void res_store_so(const cpx (&v)[16], __amdgpu_buffer
     asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" CLFA_STNT ::"v"(v[e]), "v"(voff), "s"(r), "s"(so[e]) : "memory");
 }
 // W_2M^i of the lane's register e: base * W_32^e
-template <int E> __device__ __forceinline__ cpx pair_tw_e(cpx base) {
+template <int E, bool FWD = true> __device__ __forceinline__ cpx pair_tw_e(cpx base) {
   if constexpr (E == 0) return base;
-  else return ctw<true>(base, kC32[E], kS32[E]);
+  else return ctw<FWD>(base, kC32[E], kS32[E]);
 }
 // r2c_pair_prescaled (fft_device.hpp) in six packed instructions: the conjugations and the rotation by i ride on the
 // operand modifiers.  One wave per SIMD pays for every instruction in full, so the map is written out here.
@@ -725,6 +736,101 @@ template <bool ROW0> __device__ __forceinline__ void res_pair_self_row(cpx (&v)[
   }
 }
 
+
+// ---- packed real transforms of size 2 kN = 131072, inverse (C2R): the reference's `iconv` pair map (cl_fft.cpp:192-205)
+// inside phase 1.
+//
+// The input index has the structure of the forward kernel's output: i = 16 cb + c + 256 (t + 16 e) pairs with column
+// 16 - c of column block 15 - cb, row (15 - t) + 16 (15 - e).  Phase 1 takes the column blocks in pairs A = q natural,
+// B = 15 - q loaded through mirrored lanes (q = 7 .. 0): the map is register-to-register (A in the lane's registers,
+// B in the landing registers), and B un-mirrors itself in its own exchange — the lane writes its first-pass results to
+// column slot 16 - c at position 16 (15 - t) and the natural lanes read them.  The lanes c = 0 have loaded column 0 of
+// block 16 - q (the partners of their A column): it belongs to the NEXT pair's B block, so its first-pass results go
+// to a copy buffer that the next B block's lanes c = 0 read instead of slot 0 (loads do not mind the detour; the
+// forward kernel's stores did, profiles/rfft131072_fused_r04.txt).  Columns 0 (in A_0) and 128 (block 8's, loaded
+// separately before the first pair) pair within themselves across the 16 lanes c = 0.
+// The map's two factors 1/2 ride on the four-step twiddle table (x 0.5); the untouched bins 0 and M/2 are doubled.
+// Both blocks of the next pair are loaded along the A block (two loads per hook point, into the two AGPR zones; the
+// B data then move to the landing registers); the last pair's B block comes through the landing registers directly.
+__device__ __forceinline__ void c2r_pair6(cpx a, cpx b, cpx w, cpx &oi, cpx &oj) {
+  cpx e, r, x, y;
+  asm("v_pk_add_f32 %0, %4, %5 neg_hi:[0,1]\n\t"                                                // e = a + conj(b)
+      "v_pk_add_f32 %1, %4, %5 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,1] neg_hi:[0,1]\n\t"      // r = i (a - conj(b))
+      "v_pk_mul_f32 %2, %6, %1 op_sel_hi:[0,1]\n\t"                                             // x = w r
+      "v_pk_fma_f32 %2, %6, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_add_f32 %3, %0, %2 neg_lo:[0,1] neg_hi:[1,0]\n\t"                                   // y = conj(e - x)
+      "v_pk_add_f32 %2, %0, %2"                                                                // x = e + x
+      : "=&v"(e), "=&v"(r), "=&v"(x), "=&v"(y)
+      : "v"(a), "v"(b), "v"(w));
+  oi = x;
+  oj = y;
+}
+// ... with the B value in (and its result back into) the landing register pair VB
+template <int VB> __device__ __forceinline__ void c2r_pair6_land(cpx &a, cpx w) {
+  cpx e, r, x;
+  asm volatile("v_pk_add_f32 %0, %3, v[%c5:%c6] neg_hi:[0,1]\n\t"
+               "v_pk_add_f32 %1, %3, v[%c5:%c6] op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,1] neg_hi:[0,1]\n\t"
+               "v_pk_mul_f32 %2, %4, %1 op_sel_hi:[0,1]\n\t"
+               "v_pk_fma_f32 %2, %4, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+               "v_pk_add_f32 v[%c5:%c6], %0, %2 neg_lo:[0,1] neg_hi:[1,0]\n\t"
+               "v_pk_add_f32 %2, %0, %2"
+               : "=&v"(e), "=&v"(r), "=&v"(x)
+               : "v"(a), "v"(w), "n"(VB), "n"(VB + 1));
+  a = x;
+}
+// start of a pair: the A block (raw, in v) against the B block (raw, in the landing registers), both finished in place
+__device__ __forceinline__ void res_unpair_map(cpx (&v)[16], cpx base) {
+  static_for<16>([&](auto E) {
+    constexpr int e = decltype(E)::value;
+    c2r_pair6_land<224 + 2 * (15 - e)>(v[e], pair_tw_e<e, false>(base));
+    if (e & 1) __builtin_amdgcn_sched_barrier(0);
+  });
+}
+// lanes c = 0 of a column that pairs within itself (COL0: n2 = 0, natural lanes, row n1 = t + 16 e pairs with 256 - n1,
+// rows 0 and 128 are the reference's untouched bins 0 and M/2; else n2 = 128, mirrored lanes, n1 = (15 - t) + 16 e pairs
+// with 255 - n1).  Every lane computes its own 16 values.  Called by all lanes (barrier inside).
+template <bool COL0> __device__ __forceinline__ void res_unpair_self_col(cpx (&v)[16], int c, int t, cpx base, cpx *s_c0) {
+  if (c == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) s_c0[t * 16 + e] = v[e];
+  }
+  __syncthreads();
+  if (c == 0) {
+    static_for<16>([&](auto E) {
+      constexpr int e = decltype(E)::value;
+      int idx;
+      if constexpr (COL0) {
+        const int n1 = (256 - (t + 16 * e)) & 255;
+        idx = (n1 & 15) * 16 + (n1 >> 4);
+      } else {
+        idx = (15 - t) * 16 + (15 - e);
+      }
+      const cpx ci = v[e], zp = s_c0[idx];
+      cpx oi, oj;
+      c2r_pair6(ci, zp, pair_tw_e<e, false>(base), oi, oj);
+      if constexpr (COL0 && e == 0) {
+        if (t == 0) oi = mk(2.0f * (ci.x + ci.y), 2.0f * (ci.x - ci.y));
+      }
+      if constexpr (COL0 && e == 8) {
+        if (t == 0) oi = cscale(ci, 2.0f);
+      }
+      v[e] = oi;
+      asm volatile("" : "+v"(v[e]));
+      if (e & 1) __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+}
+// zone Z1 (AGPR columns 12, 13) -> landing registers
+__device__ __forceinline__ void res_zone1_to_land() {
+  static_for<16>([&](auto E) {
+    constexpr int e = decltype(E)::value, src = 32 * (e & 7) + 2 * (kZone1 + (e >> 3));
+    asm volatile("v_accvgpr_read_b32 v[%c0], a[%c2]\n\tv_accvgpr_read_b32 v[%c1], a[%c3]" ::"n"(224 + 2 * e), "n"(225 + 2 * e), "n"(src), "n"(src + 1));
+  });
+}
+template <class H> __device__ __forceinline__ void res_issue_all(const H &h) {
+  static_for<16>([&](auto Kc) { h(Kc); });
+}
+
 }  // namespace
 
 #ifdef CLFA_RES16_PROBE
@@ -747,7 +853,8 @@ __device__ __forceinline__ void res_probe_grid_sync(unsigned long long *dbg, uns
 // slots: one 32 KiB slot per workgroup (the single row block that does not fit the CU)
 // R2C: packed real transforms of size 2 kN, forward — the same transform with the reference's pair map inside phase 2
 // (above); w2_g = the plan's pair twiddles W_2M^i (cl_fft.cpp:233-238), M entries
-template <bool FWD, bool SCALE, int PROBE = 0, bool R2C = false>
+// C2R: ... inverse — the pair map inside phase 1 (above)
+template <bool FWD, bool SCALE, int PROBE = 0, bool R2C = false, bool C2R = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_fft_res16(const cpx *data, cpx *out, cpx *__restrict__ slots,
                                                    const cpx *__restrict__ tabs_g, long batch,
                                                    unsigned long long *__restrict__ dbg = nullptr,
@@ -755,20 +862,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
 #ifndef CLFA_RES16_PROBE
   static_assert(PROBE == 0, "the timing experiments exist only in tools/res16_probe.hip (CLFA_RES16_PROBE)");
 #endif
-  static_assert(!R2C || (FWD && SCALE && PROBE == 0), "the fused pair map is the forward one");
-  __shared__ __attribute__((aligned(16))) cpx s_tab[R2C ? kTabSizeR : kTabSize];
+  static_assert(!R2C || (FWD && SCALE && PROBE == 0 && !C2R), "the fused forward pair map");
+  static_assert(!C2R || (!FWD && !SCALE && PROBE == 0), "the fused inverse pair map");
+  __shared__ __attribute__((aligned(16))) cpx s_tab[(R2C || C2R) ? kTabSizeR : kTabSize];
   __shared__ __attribute__((aligned(16))) cpx s_x[kXSize];
   __shared__ __attribute__((aligned(16))) char s_spill[256 * kSpillStride];
-  __shared__ __attribute__((aligned(16))) cpx s_c0[R2C ? 256 : 1];
+  __shared__ __attribute__((aligned(16))) cpx s_c0[(R2C || C2R) ? 256 : 1];
+  __shared__ __attribute__((aligned(16))) cpx s_col0[C2R ? 2 * kXA : 1];   // first-pass results of the B blocks' column 0
   acc_claim_all();
   const int tid = threadIdx.x;
   for (int i = tid; i < kTabSize; i += 256) {
     cpx w = tabs_g[i];
     // exact: powers of two (R2C: the pair map's 1/2 as well)
     if (SCALE && i >= kTabLo && i < kTabHi) w = cscale(w, R2C ? 0.5f / (float)kN : 1.0f / (float)kN);
+    if (C2R && i >= kTabLo && i < kTabHi) w = cscale(w, 0.5f);   // the inverse map's two factors 1/2
     s_tab[i] = w;
   }
-  if constexpr (R2C) {
+  if constexpr (R2C || C2R) {
     s_tab[kTabPair + tid] = w2_g[tid];
     if (tid < 16) s_tab[kTabPair + 256 + tid] = w2_g[256 * tid];
   }
@@ -798,6 +908,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     L.voff = tm * 2048 + cm * 8;
     L.xb_r = s_x + cm * kXB + tm;
     L.tw_row = s_tab + kTabTw + 16 * tm;
+    return L;
+  };
+  // C2R, the B block of a pair: first-pass results go to column slot 16 - c at position 16 (15 - t); the lanes c = 0
+  // hold the NEXT pair's column 0 (-> copy buffer `save_w`) and read this block's from the previous pair's (`save_r`)
+  [[maybe_unused]] auto lane_b = [&](cpx *save_w, const cpx *save_r) {
+    ResLane L = lane();
+    const int cm = 16 - L.c, tm = 15 - L.t;
+    L.xa_w = (L.c ? s_x + cm * kXA : save_w) + 16 * tm;
+    if (L.c == 0) L.xa_r = save_r + L.t;
     return L;
   };
   const int rot = (PROBE & kProbeRotate) ? (int)(blockIdx.x & 15) : 0;   // probe only: 0 in the library
@@ -850,7 +969,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
   }
 #endif
   // blocks 0 and 1 of the first transform
-  if constexpr (!(PROBE & kProbeNoLoad)) {
+  if constexpr (C2R) {
+    // the first pair: block 7 -> Z0, block 8 mirrored -> landing registers, column 128 (lanes c = 0, mirrored rows) -> Z1
+    const ResLane L0 = lane();
+    const cpx *x0 = data + b * (long)kN;
+    res_issue_all(HookAcc<kZone0>{res_rsrc(x0 + 7 * 16), L0.voff, so});
+    res_issue_all(HookLand{res_rsrc(x0 + 8 * 16), (15 - L0.t) * 2048 + (16 - L0.c) * 8, so});
+    res_issue_all(HookAcc<kZone1>{res_rsrc(x0 + 8 * 16), (15 - L0.t) * 2048 + L0.c * 8, so});
+  } else if constexpr (!(PROBE & kProbeNoLoad)) {
     const ResLane L0 = lane();
     res_load_acc<kZone0>(data + b * (long)kN + (rot & 15) * 16, L0.voff);
     res_load_land(data + b * (long)kN + ((1 + rot) & 15) * 16, L0.voff);
@@ -867,6 +993,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     unsigned long long t0 = 0;
     if constexpr (PROBE & kProbeStamps) t0 = __builtin_amdgcn_s_memtime();
 #endif
+    if constexpr (C2R) {
+      // ---- phase 1 of the packed real inverse: pairs of column blocks, the reference's iconv map first (see above)
+      res_wait_vm<0>();
+      {   // column 128 (lanes c = 0, out of Z1): pairs within itself; its first-pass results -> copy buffer 0
+        const ResLane L = lane();
+        acc_fetch_raw<kZone1>(v, std::make_integer_sequence<int, 8>());
+        const cpx bm = cmul(s_tab[kTabPair + 128], s_tab[kTabPair + 256 + 15 - L.t]);
+        res_unpair_self_col<false>(v, L.c, L.t, bm, s_c0);
+        if (L.c == 0) {
+          const HookNone none;
+          CLFA_DFT16_H(false, v, none, kMapColA);
+          f4 *pw = reinterpret_cast<f4 *>(s_col0 + 16 * (15 - L.t));
+#pragma unroll
+          for (int i = 0; i < 8; i++) pw[i] = pack2(v[2 * i], v[2 * i + 1]);
+        }
+      }
+      // MODE 0: pairs 0..5, 1: pair 6 (the last pair's B block comes through the landing registers), 2: pair 7
+      auto pair_step = [&](auto MODE, int p) {
+        constexpr int mode = decltype(MODE)::value;
+        const int q = 7 - p;
+        {
+          const ResLane L = lane();
+          // loads of this pair: issued along the previous pair's A block (pair 7's B block: along pair 6's B block);
+          // younger than they are only the slot stores of the blocks since (pair 0: waited for above)
+          if (mode == 2) res_wait_vm<kC2rWait ? 1 : 0>();
+          else if (p > 0) res_wait_vm<kC2rWait ? 2 : 0>();
+          acc_fetch_raw<kZone0>(v, std::make_integer_sequence<int, 8>());
+          if (mode == 1 || (mode == 0 && p > 0)) res_zone1_to_land();
+          const cpx base = cmul(s_tab[kTabPair + 16 * q + L.c], s_tab[kTabPair + 256 + L.t]);
+          if constexpr (mode == 2) {
+            res_unpair_self_col<true>(v, L.c, L.t, base, s_c0);   // column 0
+            if (L.c != 0) res_unpair_map(v, base);
+          } else {
+            res_unpair_map(v, base);
+          }
+          const int voff_m = (15 - L.t) * 2048 + (16 - L.c) * 8;
+          if constexpr (mode == 0) {
+            res_col_block<false, 0>(v, L, q, s_tab, s_x,
+                                    Hook2<HookAcc<kZone0>, HookAcc<kZone1>>{HookAcc<kZone0>{res_rsrc(x + (q - 1) * 16), L.voff, so},
+                                                                           HookAcc<kZone1>{res_rsrc(x + (16 - q) * 16), voff_m, so}});
+          } else if constexpr (mode == 1) {
+            res_col_block<false, 0>(v, L, q, s_tab, s_x, HookAcc<kZone0>{res_rsrc(x + (q - 1) * 16), L.voff, so});
+          } else {
+            res_col_block<false, 0>(v, L, q, s_tab, s_x);
+          }
+          res_deposit<0, false, true>(v, L, q, K, slot);
+        }
+        {
+          const ResLane L = lane_b(s_col0 + ((p + 1) & 1) * kXA, s_col0 + (p & 1) * kXA);
+          res_land_fetch(v);
+          if constexpr (mode == 0) {
+            res_col_block<false, 0>(v, L, 15 - q, s_tab, s_x);
+          } else if constexpr (mode == 1) {
+            // block 15 mirrored (its lanes c = 0 have no partner column to fetch: out of the buffer's range)
+            const int voff_m = L.c ? (15 - L.t) * 2048 + (16 - L.c) * 8 : (int)0x80000000;
+            res_col_block<false, 0>(v, L, 15 - q, s_tab, s_x, HookLand{res_rsrc(x + 15 * 16), voff_m, so});
+          } else {
+            res_col_block<false, 0>(v, L, 15 - q, s_tab, s_x, HookSlot{slot, L.slot_off, so});
+          }
+          res_deposit<0, mode == 2, true>(v, L, 15 - q, K, slot);
+        }
+      };
+#pragma unroll 1
+      for (int p = 0; p < 6; p++) pair_step(ic<0>(), p);
+      pair_step(ic<1>(), 6);
+      pair_step(ic<2>(), 7);
+    } else {
     // ---- phase 1: four column blocks per round (landing zones Z0, v[224:255], Z1, v[224:255]); on entry
     // block 0 is in (or on its way to) Z0 and block 1 on its way to the landing registers
 #pragma unroll 1
@@ -881,6 +1074,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     res_phase1_block<FWD, PROBE, kZone1, -1, false>(v, lane(), x, 14, rot, so, K, slot, s_tab, s_x);
     if constexpr (R2C) res_phase1_block<FWD, PROBE, -1, -1, false, 0, false>(v, lane(), x, 15, rot, so, K, slot, s_tab, s_x);
     else res_phase1_block<FWD, PROBE, -1, -1, false, 0, true>(v, lane(), x, 15, rot, so, K, slot, s_tab, s_x);
+    }   // !C2R
 #ifdef CLFA_RES16_PROBE
     if constexpr (PROBE & kProbeStamps) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -988,14 +1182,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       const ResLane L = lane();
       int rb;
       switch (it) {
-#define CLFA_C(k, r) case k: res_fetch_static<r>(v, L, K); rb = r; break;
+#define CLFA_C(k, r) case k: res_fetch_static<r, C2R>(v, L, K); rb = r; break;
         CLFA_C(1, 8) CLFA_C(2, 9) CLFA_C(3, 10) CLFA_C(4, 11) CLFA_C(5, 12) CLFA_C(6, 13) CLFA_C(7, 14) CLFA_C(8, 15)
         CLFA_C(9, 4) CLFA_C(10, 5) CLFA_C(11, 6) CLFA_C(12, 7) CLFA_C(13, 0)
 #undef CLFA_C
         default: res_fetch_static<1>(v, L, K); rb = 1; break;
       }
       if constexpr (!(PROBE & kProbeNoLoad)) {
-        if (it == 13) res_load_acc<kZone0>(xn + (rot & 15) * 16, L.voff);
+        if (it == 13) {
+          if constexpr (C2R) res_issue_all(HookAcc<kZone0>{res_rsrc(xn + 7 * 16), L.voff, so});   // the next transform's block 7
+          else res_load_acc<kZone0>(xn + (rot & 15) * 16, L.voff);
+        }
       }
       if constexpr (!(PROBE & kProbeNoStore)) {
         res_row_block<FWD, PROBE>(v, L, HookStore{res_rsrc(y + ((rb_prev + rot) & 15) * 16), L.voff, so});
@@ -1015,7 +1212,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       }
       res_store<PROBE>(v, res_rsrc(y + ((2 + rot) & 15) * 16), L.voff);
       // the next transform's block 1 -> landing registers (after this block's parked stores have been issued)
-      if constexpr (!(PROBE & kProbeNoLoad)) res_load_land(xn + ((1 + rot) & 15) * 16, L.voff);
+      if constexpr (C2R) {   // the next transform's block 8 (mirrored) and column 128
+        res_issue_all(HookLand{res_rsrc(xn + 8 * 16), (15 - L.t) * 2048 + (16 - L.c) * 8, so});
+        res_issue_all(HookAcc<kZone1>{res_rsrc(xn + 8 * 16), (15 - L.t) * 2048 + L.c * 8, so});
+      } else if constexpr (!(PROBE & kProbeNoLoad)) res_load_land(xn + ((1 + rot) & 15) * 16, L.voff);
     }
     }   // !R2C
 #ifdef CLFA_RES16_PROBE
@@ -1072,6 +1272,15 @@ hipError_t launch_fft_res16(bool fwd, bool scale, const cpx *data, cpx *out, cpx
   else if (fwd) hipLaunchKernelGGL((k_fft_res16<true, false>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch);
   else if (!scale) hipLaunchKernelGGL((k_fft_res16<false, false>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_crfft_res16(const cpx *data, cpx *out, cpx *slots, const cpx *tabs, const cpx *w2, long batch,
+                              const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  const int grid = (int)(batch < di.num_cus ? batch : di.num_cus);
+  hipLaunchKernelGGL((k_fft_res16<false, false, 0, false, true>), dim3(grid), dim3(256), 0, s, data, out, slots, tabs, batch,
+                     (unsigned long long *)nullptr, w2);
   return hipGetLastError();
 }
 

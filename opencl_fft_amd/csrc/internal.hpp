@@ -74,6 +74,9 @@ hipError_t launch_fft_res16(bool fwd, bool scale, const cpx *data, cpx *out, cpx
 // phase (w2 = the plan's pair twiddles, 65536 entries) — one HBM pass instead of the transform + k_r2c_pack
 hipError_t launch_rfft_res16(const cpx *data, cpx *out, cpx *slots, const cpx *tabs, const cpx *w2, long batch,
                              const DeviceInfo &di, hipStream_t s);
+// ... and the inverse: the reference's iconv map inside the first phase (w2 = the inverse plan's pair twiddles)
+hipError_t launch_crfft_res16(const cpx *data, cpx *out, cpx *slots, const cpx *tabs, const cpx *w2, long batch,
+                              const DeviceInfo &di, hipStream_t s);
 // n = 2^17 .. 2^kBigMaxLog (extension: the reference overflows above 65536): columns + rows + transpose
 constexpr int kBigMaxLog = 24;
 struct BigGeom {

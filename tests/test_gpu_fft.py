@@ -311,6 +311,41 @@ def test_rfft131072_forward_one_pass_ragged(batch):
     assert np.array_equal(src.cpu().numpy(), r)
 
 
+@pytest.mark.parametrize("batch", [65, 257, 300, 777])
+def test_rfft131072_inverse_one_pass_ragged(batch):
+    """Clrfft inverse (cl_fft.cpp:283-294) of size 131072 with more than CUs / 4 transforms: ONE launch — the reference's
+    `iconv` pair map (cl_fft.cpp:192-205) inside the FIRST phase of the resident kernel (column blocks in mirrored pairs).
+    Arbitrary packed spectra (not only those of real signals: bin 0's imaginary part and bin M/2 are free) against the
+    oracle; single-bin spectra on the bins the map treats specially (0, M/2) and on the columns that pair across lanes
+    (bins 256 k, 128 + 256 k) and one step further (16 q, 16 (16 - q)); out of place bit for bit the same."""
+    import torch
+    size, m = 131072, 65536
+    rng = np.random.default_rng(1000 + batch)
+    c = ((rng.random((batch, m), dtype=np.float32) * 2 - 1) + 1j * (rng.random((batch, m), dtype=np.float32) * 2 - 1)).astype(np.complex64)
+    c *= np.float32(1 / 256)
+    bins = [0, m // 2, 256, 128, 128 + 256 * 77, 256 * 255, 16, 240, 112, 144, 65535, 1, 4096 + 16 * 5, m - 4096 - 16 * 5]
+    for k, bin_ in enumerate(bins):   # the last transforms of the batch: one bin each
+        c[batch - 1 - k] = 0
+        c[batch - 1 - k, bin_] = 1 - 0.5j
+    i = fa.Clrfft(0, size, False)
+    assert i.get_error() == 0 and i.kernel_name() == "k_fft_res16"
+    d = torch.from_numpy(c.view(np.float32).reshape(batch, size).copy()).cuda()
+    assert i.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().reshape(batch, size)
+    pick = sorted(set([0, 1, batch // 2, 255 % batch, 256 % batch] + [batch - 1 - k for k in range(len(bins))]))
+    want = oracle.rfft_inverse(c[pick])
+    for j, b in enumerate(pick):
+        assert_parity(got[b], want[j], what="irfft 131072 batch %d transform %d" % (batch, b))
+    src = torch.from_numpy(c.view(np.float32).reshape(batch, size).copy()).cuda()
+    keep = src.clone()
+    dst = torch.full_like(src, float("nan"))
+    assert i.exec_device_oop(src, dst, batch) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst.view(torch.int32), d.view(torch.int32))
+    assert torch.equal(src.view(torch.int32), keep.view(torch.int32))
+
+
 @pytest.mark.parametrize("n,batch", [(16384, 70), (16384, 300), (32768, 70), (32768, 300), (65536, 70), (65536, 300)])
 def test_cfft_persistent_kernel_ragged(n, batch):
     """the persistent four-step kernel (intermediate in LDS + registers) with batch counts that are
