@@ -262,29 +262,35 @@ template <int K> using ic = std::integral_constant<int, K>;
 struct HookNone {
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {}
 };
-template <int CB> struct HookAcc {   // -> AGPR columns CB, CB + 1 (a landing zone)
+// KEEP: a plain (cached) load instead of the streaming one — the mirrored loads of the packed real inverse kernel touch
+// every line twice, one pair apart (15 of its 16 columns, then the last), and the second touch should find it in L2
+template <int CB, bool KEEP = false> struct HookAcc {   // -> AGPR columns CB, CB + 1 (a landing zone)
   __amdgpu_buffer_rsrc_t r;
   int voff;
   const int (&so)[16];
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
     constexpr int lo = 32 * (K & 7) + 2 * (K < 8 ? CB : CB + 1);
     if constexpr (K == 0)   // the descriptor's SGPRs may be fresh from SALU: 5 wait states before VMEM reads them
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
+      asm volatile("s_nop 4" ::"s"(r));
+    if constexpr (KEEP)
+      asm volatile("buffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen" ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
     else
       asm volatile("buffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
   }
 };
-struct HookLand {   // -> landing registers v[224:255]
+template <bool KEEP = false> struct HookLandT {   // -> landing registers v[224:255]
   __amdgpu_buffer_rsrc_t r;
   int voff;
   const int (&so)[16];
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
-    if constexpr (K == 0)
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+    if constexpr (K == 0) asm volatile("s_nop 4" ::"s"(r));
+    if constexpr (KEEP)
+      asm volatile("buffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
     else
       asm volatile("buffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
   }
 };
+using HookLand = HookLandT<false>;
 // block 15 of phase 1 has nothing left to prefetch: its hooks bring the global slot's row block back
 // (columns 0..14; column 15 is still in the lane's registers then) into v[224:253]; agent scope (sc1): the
 // loads bypass this CU's L1, which may still hold the previous transform's lines
@@ -579,10 +585,15 @@ __device__ __forceinline__ void res_phase1_block(cpx (&v)[16], const ResLane &L,
 // rows k1 = 0 (in A_0) and k1 = 128 (in B_7) pair within themselves, across the 16 lanes c = 0, through 2 KiB of LDS.
 // Pair twiddles W_2M^i = W_2M^(16 q + c) * W_512^t * W_32^e: two lookups (the first 256 entries of the plan's w2 table
 // and every 256th) and compile-time constants.  The map's 1/2 rides on the 1/N of the table (r2c_pair_prescaled).
+// build switches of the inverse kernel (A/B and debugging; the library's choice is the default)
 #ifndef CLFA_C2R_WAIT
-#define CLFA_C2R_WAIT 1
+#define CLFA_C2R_WAIT 1      // 0: every wait of its phase 1 is vmcnt(0)
 #endif
-constexpr bool kC2rWait = CLFA_C2R_WAIT;   // 0 (dev builds): every wait of the inverse kernel's phase 1 is vmcnt(0)
+#ifndef CLFA_C2R_KEEP_A
+#define CLFA_C2R_KEEP_A 1    // its natural loads cached as well: per 1024 transforms all streaming 0.265 ms, the mirrored
+#endif                       // loads cached 0.253, all cached 0.245 (profiles/rfft131072_fused_r04.txt)
+constexpr bool kC2rWait = CLFA_C2R_WAIT;
+constexpr bool kC2rKeepA = CLFA_C2R_KEEP_A;
 constexpr int kTabPair = kTabSize;   // [W_2M^k, k < 256 | W_512^t, t < 16]
 constexpr int kTabSizeR = kTabSize + 272;
 constexpr int kParkAcc = 224;        // B' results parked in a[224:255] (keep row 15's registers, fetched first)
@@ -973,9 +984,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
     // the first pair: block 7 -> Z0, block 8 mirrored -> landing registers, column 128 (lanes c = 0, mirrored rows) -> Z1
     const ResLane L0 = lane();
     const cpx *x0 = data + b * (long)kN;
-    res_issue_all(HookAcc<kZone0>{res_rsrc(x0 + 7 * 16), L0.voff, so});
-    res_issue_all(HookLand{res_rsrc(x0 + 8 * 16), (15 - L0.t) * 2048 + (16 - L0.c) * 8, so});
-    res_issue_all(HookAcc<kZone1>{res_rsrc(x0 + 8 * 16), (15 - L0.t) * 2048 + L0.c * 8, so});
+    res_issue_all(HookAcc<kZone0, kC2rKeepA>{res_rsrc(x0 + 7 * 16), L0.voff, so});
+    res_issue_all(HookLandT<true>{res_rsrc(x0 + 8 * 16), (15 - L0.t) * 2048 + (16 - L0.c) * 8, so});
+    res_issue_all(HookAcc<kZone1, true>{res_rsrc(x0 + 8 * 16), (15 - L0.t) * 2048 + L0.c * 8, so});
   } else if constexpr (!(PROBE & kProbeNoLoad)) {
     const ResLane L0 = lane();
     res_load_acc<kZone0>(data + b * (long)kN + (rot & 15) * 16, L0.voff);
@@ -1031,10 +1042,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
           const int voff_m = (15 - L.t) * 2048 + (16 - L.c) * 8;
           if constexpr (mode == 0) {
             res_col_block<false, 0>(v, L, q, s_tab, s_x,
-                                    Hook2<HookAcc<kZone0>, HookAcc<kZone1>>{HookAcc<kZone0>{res_rsrc(x + (q - 1) * 16), L.voff, so},
-                                                                           HookAcc<kZone1>{res_rsrc(x + (16 - q) * 16), voff_m, so}});
+                                    Hook2<HookAcc<kZone0, kC2rKeepA>, HookAcc<kZone1, true>>{HookAcc<kZone0, kC2rKeepA>{res_rsrc(x + (q - 1) * 16), L.voff, so},
+                                                                                 HookAcc<kZone1, true>{res_rsrc(x + (16 - q) * 16), voff_m, so}});
           } else if constexpr (mode == 1) {
-            res_col_block<false, 0>(v, L, q, s_tab, s_x, HookAcc<kZone0>{res_rsrc(x + (q - 1) * 16), L.voff, so});
+            res_col_block<false, 0>(v, L, q, s_tab, s_x, HookAcc<kZone0, kC2rKeepA>{res_rsrc(x + (q - 1) * 16), L.voff, so});
           } else {
             res_col_block<false, 0>(v, L, q, s_tab, s_x);
           }
@@ -1048,7 +1059,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
           } else if constexpr (mode == 1) {
             // block 15 mirrored (its lanes c = 0 have no partner column to fetch: out of the buffer's range)
             const int voff_m = L.c ? (15 - L.t) * 2048 + (16 - L.c) * 8 : (int)0x80000000;
-            res_col_block<false, 0>(v, L, 15 - q, s_tab, s_x, HookLand{res_rsrc(x + 15 * 16), voff_m, so});
+            res_col_block<false, 0>(v, L, 15 - q, s_tab, s_x, HookLandT<true>{res_rsrc(x + 15 * 16), voff_m, so});
           } else {
             res_col_block<false, 0>(v, L, 15 - q, s_tab, s_x, HookSlot{slot, L.slot_off, so});
           }
@@ -1190,7 +1201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       }
       if constexpr (!(PROBE & kProbeNoLoad)) {
         if (it == 13) {
-          if constexpr (C2R) res_issue_all(HookAcc<kZone0>{res_rsrc(xn + 7 * 16), L.voff, so});   // the next transform's block 7
+          if constexpr (C2R) res_issue_all(HookAcc<kZone0, kC2rKeepA>{res_rsrc(xn + 7 * 16), L.voff, so});   // the next transform's block 7
           else res_load_acc<kZone0>(xn + (rot & 15) * 16, L.voff);
         }
       }
@@ -1213,8 +1224,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
       res_store<PROBE>(v, res_rsrc(y + ((2 + rot) & 15) * 16), L.voff);
       // the next transform's block 1 -> landing registers (after this block's parked stores have been issued)
       if constexpr (C2R) {   // the next transform's block 8 (mirrored) and column 128
-        res_issue_all(HookLand{res_rsrc(xn + 8 * 16), (15 - L.t) * 2048 + (16 - L.c) * 8, so});
-        res_issue_all(HookAcc<kZone1>{res_rsrc(xn + 8 * 16), (15 - L.t) * 2048 + L.c * 8, so});
+        res_issue_all(HookLandT<true>{res_rsrc(xn + 8 * 16), (15 - L.t) * 2048 + (16 - L.c) * 8, so});
+        res_issue_all(HookAcc<kZone1, true>{res_rsrc(xn + 8 * 16), (15 - L.t) * 2048 + L.c * 8, so});
       } else if constexpr (!(PROBE & kProbeNoLoad)) res_load_land(xn + ((1 + rot) & 15) * 16, L.voff);
     }
     }   // !R2C
