@@ -22,7 +22,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                 host cores over a bounded sample — a reported baseline, not the target
   config.other_workloads   (N = 1 only) configs[2] and configs[3] of BASELINE.json — r2c + c2r of size
                 16384 x 8192 and the 256-channel partitioned convolution — timed in the same run with the
-                same machinery, each with ms_per_step and its own roofline block
+                same machinery, each with ms_per_step and its own roofline block; plus (not a BASELINE config)
+                r2c + c2r of size 131072 x 2048, the largest real size of the reference's range
   ms_per_step_cold / roofline.frac_cold   the same K steps after the same W warm-up steps taken FIRST, before
                 the full-size self-check (the chip is still inside its ~20 ms start-up clock ramp then);
                 config.effective_warmup_launches counts what ran before the headline's timed region
@@ -190,6 +191,22 @@ class Workload:
             self.kernel, self.tkey = self.plans[0].kernel_name(), "c2c65536"
             self.metric = "Gsamples/s for batched 1D FFT (N=65536, float32) + achieved HBM GB/s vs peak"
             self.direction = "steps alternate forward/inverse plans"
+        elif name == "rfft131072":
+            # not a BASELINE config: the largest packed real size of the reference's range (cl_fft.cpp:32), in ONE HBM pass
+            # since round 4 (the resident kernel with the reference's pair maps inside)
+            size, batch = 131072, batch_override or 2048
+            self.batch, self.n = batch, size
+            self.data = torch.rand((batch, size), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+            self.plans = [fa.Clrfft(local, size, True), fa.Clrfft(local, size, False)]
+            for p in self.plans:
+                assert p.get_error() == 0, p.get_log()
+            self.units = batch * size
+            self.alg_bytes = 8.0 * self.units
+            self.step = lambda k: self.plans[k & 1].exec_device(self.data, batch, stream.cuda_stream)
+            self.workload = "r2c then c2r, size=131072 x %d batches per GPU, packed in place (largest real size of the reference's range)" % batch
+            self.kernel, self.tkey = self.plans[0].kernel_name(), "rfft131072"
+            self.metric = "Gsamples/s (real samples) for batched r2c/c2r FFT size=131072"
+            self.direction = "steps alternate r2c / c2r plans"
         elif name == "rfft":
             size, batch = 16384, batch_override or 8192
             self.batch, self.n = batch, size
@@ -428,7 +445,7 @@ def main():
     others = None
     if world == 1 and not a.no_other_workloads and not a.series_out and a.batch == 0:
         others, other_names = {}, []
-        for name in ("c2c", "rfft", "pconv"):
+        for name in ("c2c", "rfft", "pconv", "rfft131072"):
             if name == a.workload:
                 continue
             o = Workload(name, fa, torch, dev, local, rank, world, 0, stream)
@@ -537,6 +554,8 @@ def main():
                     others["rfft"]["cpu_baseline"] = cpu_baseline_rfft(16384, 32768)
                 if "pconv" in others:
                     others["pconv"]["cpu_baseline"] = cpu_baseline_pconv(96256, 1024, 4000)
+                if "rfft131072" in others:
+                    others["rfft131072"]["cpu_baseline"] = cpu_baseline_rfft(131072, 2048)
         else:
             rec["cpu_baseline"] = None
         print(json.dumps(rec), flush=True)

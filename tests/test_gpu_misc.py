@@ -148,7 +148,8 @@ def test_bench_default_line_carries_every_single_gpu_config():
     assert r["ms_per_step_cold"] > 0 and 0 < r["roofline"]["frac_cold"] < 1 and 0 < r["roofline"]["frac"] < 1
     assert r["config"]["effective_warmup_launches"] >= 2 * 2 + 6 + 4
     ow = r["config"]["other_workloads"]
-    assert set(ow) == {"rfft", "pconv"}
+    assert set(ow) == {"rfft", "pconv", "rfft131072"}
+    assert ow["rfft131072"]["roofline"]["kernel"] == "k_fft_res16" and ow["rfft131072"]["full_size_selfcheck"]["roundtrip_max_abs"] < 2e-5
     for k, v in ow.items():
         assert v["ms_per_step"] > 0 and v["steps"] >= 100 and 0 < v["roofline"]["frac"] < 1 and v["roofline"]["kernel"]
         assert v["roofline"]["bound"] == "hbm" and v["roofline"]["peak"] == 8000.0
