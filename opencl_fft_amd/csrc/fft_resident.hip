@@ -585,9 +585,9 @@ __device__ __forceinline__ void res_phase1_block(cpx (&v)[16], const ResLane &L,
 // rows k1 = 0 (in A_0) and k1 = 128 (in B_7) pair within themselves, across the 16 lanes c = 0, through 2 KiB of LDS.
 // Pair twiddles W_2M^i = W_2M^(16 q + c) * W_512^t * W_32^e: two lookups (the first 256 entries of the plan's w2 table
 // and every 256th) and compile-time constants.  The map's 1/2 rides on the 1/N of the table (r2c_pair_prescaled).
-// build switches of the inverse kernel (A/B and debugging; the library's choice is the default)
+// build switches of the packed real variants (A/B and debugging; the library's choice is the default)
 #ifndef CLFA_C2R_WAIT
-#define CLFA_C2R_WAIT 1      // 0: every wait of its phase 1 is vmcnt(0)
+#define CLFA_C2R_WAIT 1      // 0: every counted wait of the two packed real variants is vmcnt(0) (tools/check_waits.py)
 #endif
 #ifndef CLFA_C2R_KEEP_A
 #define CLFA_C2R_KEEP_A 1    // its natural loads cached as well: per 1024 transforms all streaming 0.265 ms, the mirrored
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
             case 1: res_fetch_static<1>(v, L, K); break;
             case 2: res_fetch_static<2>(v, L, K); break;
             case 3:   // the slot's block: loaded along block A_2; the 16 stores of block B_2 are younger
-              res_wait_vm<16>();
+              res_wait_vm<kC2rWait ? 16 : 0>();
               acc_fetch_flat<kSlotAcc>(v);
               break;
             case 4: res_fetch_static<4>(v, L, K); break;
