@@ -12,8 +12,15 @@ def main(src, tag, key, kernel_substr, root):
     dst = os.path.join(root, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
     newest = lambda files: sorted(files, key=os.path.getmtime)[-1:]   # gpurun_out accumulates earlier runs
-    for f in newest(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)):
+    # (the bench times the unmodified reference in a child process: rocprofv3 traces that one too — its stats file holds the
+    # reference's OpenCL kernels `fft` / `reorder` and is kept beside ours)
+    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    ours = [f for f in stats if kernel_substr in open(f).read()]
+    for f in newest(ours):
         shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+        for g in stats:
+            if g not in ours and abs(os.path.getmtime(g) - os.path.getmtime(f)) < 300:
+                shutil.copy(g, os.path.join(dst, "reference_opencl_kernel_stats.csv"))
     for f in ("bench_unprofiled.json", "bench_driver_cmdline.json", "series_steps20.txt", "series_steps100.txt", "series_cold_start.txt", "summary.json"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "summary.json" else "pmc_summary.json"))
@@ -21,7 +28,8 @@ def main(src, tag, key, kernel_substr, root):
     counter_files = []
     for d in glob.glob(os.path.join(src, "pmc_*")):
         if os.path.isdir(d):
-            counter_files += newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
+            cands = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            counter_files += newest([f for f in cands if kernel_substr in open(f).read()])   # (not the reference child's)
     for f in counter_files:
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
