@@ -45,6 +45,10 @@
 // read 16 x b64, conflict-free (layouts below).  The four-step twiddles W_N^(n2 (t + 16 e)) =
 // b * s^e come from one two-level lookup (b), four exact table values s, s^2, s^4, s^8 and a
 // product tree (15 complex multiplies for 16 values); the forward 1/N rides on the table of b.
+//
+// The same kernel carries the packed real transforms of size 131072 (the largest of the reference's range,
+// cl_fft.cpp:208-211, 267-296) in one pass as well: template flags R2C (the reference's `conv` pair map inside phase 2) and
+// C2R (`iconv` inside phase 1) — sections "packed real transforms ... forward / inverse" below.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -585,6 +589,7 @@ __device__ __forceinline__ void res_phase1_block(cpx (&v)[16], const ResLane &L,
 // rows k1 = 0 (in A_0) and k1 = 128 (in B_7) pair within themselves, across the 16 lanes c = 0, through 2 KiB of LDS.
 // Pair twiddles W_2M^i = W_2M^(16 q + c) * W_512^t * W_32^e: two lookups (the first 256 entries of the plan's w2 table
 // and every 256th) and compile-time constants.  The map's 1/2 rides on the 1/N of the table (r2c_pair_prescaled).
+
 // build switches of the packed real variants (A/B and debugging; the library's choice is the default)
 #ifndef CLFA_C2R_WAIT
 #define CLFA_C2R_WAIT 1      // 0: every counted wait of the two packed real variants is vmcnt(0) (tools/check_waits.py)
