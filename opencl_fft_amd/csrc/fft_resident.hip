@@ -386,6 +386,59 @@ __device__ __forceinline__ void dft16_hp(cpx (&v)[16], const H &hook) {
 #pragma unroll
     for (int q1 = 0; q1 < 4; q1++) v[q0 + 4 * q1] = x[4 * q0 + q1];
 }
+// The last four butterflies of a row block's second pass with their results written straight into the landing registers
+// (v[224 + 2 k] for result k): the block's results are stored from there along the next block, and the 16 moves of
+// res_stage() are 3 % of this kernel's VALU instructions — which one wave per SIMD pays in full.  Result k = q0 + 4 q1 of
+// butterfly q0 overwrites landing register k only after hook point k has issued its store (hooks 0..13 precede the first
+// of these butterflies, 14 follows the first, 15 the second; butterfly q0 writes k = q0, q0 + 4, q0 + 8, q0 + 12).
+#define CLFA_PLUS ""
+#define CLFA_MINUS " neg_lo:[0,1] neg_hi:[0,1]"
+#define CLFA_ROTF " op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"   /* x + (-i) y */
+#define CLFA_ROTI " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"   /* x + (+i) y */
+#define CLFA_BF4_LAND(M02A, M02B, MR1, MR3)                                                              \
+  asm volatile("v_pk_add_f32 %0, %4, %6" M02A "\n\t"                                                     \
+               "v_pk_add_f32 %1, %4, %6" M02B "\n\t"                                                     \
+               "v_pk_add_f32 %2, %5, %7\n\t"                                                             \
+               "v_pk_add_f32 %3, %5, %7" CLFA_MINUS "\n\t"                                               \
+               "v_pk_add_f32 v[%c8:%c9], %0, %2\n\t"                                                     \
+               "v_pk_add_f32 v[%c10:%c11], %1, %3" MR1 "\n\t"                                            \
+               "v_pk_add_f32 v[%c12:%c13], %0, %2" CLFA_MINUS "\n\t"                                     \
+               "v_pk_add_f32 v[%c14:%c15], %1, %3" MR3                                                   \
+               : "=&v"(s02), "=&v"(d02), "=&v"(s13), "=&v"(d13)                                          \
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(224 + 2 * Q0), "n"(225 + 2 * Q0), "n"(232 + 2 * Q0), \
+                 "n"(233 + 2 * Q0), "n"(240 + 2 * Q0), "n"(241 + 2 * Q0), "n"(248 + 2 * Q0), "n"(249 + 2 * Q0))
+template <bool FWD, bool ROT2, int Q0> __device__ __forceinline__ void bf4_land(cpx a0, cpx a1, cpx a2, cpx a3) {
+  cpx s02, d02, s13, d13;
+  if constexpr (FWD && !ROT2) CLFA_BF4_LAND(CLFA_PLUS, CLFA_MINUS, CLFA_ROTF, CLFA_ROTI);
+  if constexpr (!FWD && !ROT2) CLFA_BF4_LAND(CLFA_PLUS, CLFA_MINUS, CLFA_ROTI, CLFA_ROTF);
+  if constexpr (FWD && ROT2) CLFA_BF4_LAND(CLFA_ROTF, CLFA_ROTI, CLFA_ROTF, CLFA_ROTI);
+  if constexpr (!FWD && ROT2) CLFA_BF4_LAND(CLFA_ROTI, CLFA_ROTF, CLFA_ROTI, CLFA_ROTF);
+}
+#undef CLFA_BF4_LAND
+// dft16_hp whose results end in the landing registers (nothing is left in v)
+template <bool FWD, class H, int P0, int P1, int P2, int P3, int P4, int P5, int P6, int P7>
+__device__ __forceinline__ void dft16_hp_land(cpx (&v)[16], const H &hook) {
+  bf4<FWD>(v[0], v[4], v[8], v[12]);
+  hook_at<P0>(hook);
+  bf4<FWD>(v[1], v[5], v[9], v[13]);
+  hook_at<P1>(hook);
+  bf4<FWD>(v[2], v[6], v[10], v[14]);
+  hook_at<P2>(hook);
+  bf4<FWD>(v[3], v[7], v[11], v[15]);
+  ctw2<FWD>(v[4 + 1], kC16, kS16, v[4 + 2], kC8, kC8);
+  hook_at<P3>(hook);
+  ctw2<FWD>(v[4 + 3], kS16, kC16, v[8 + 1], kC8, kC8);
+  ctw2<FWD>(v[8 + 3], -kC8, kC8, v[12 + 1], kS16, kC16);
+  hook_at<P4>(hook);
+  ctw2<FWD>(v[12 + 2], -kC8, kC8, v[12 + 3], -kC16, -kS16);
+  static_assert(P4 >= 13 && P5 == 14 && P6 == 15 && P7 < 0, "landing register k is free once hook k has issued its store");
+  bf4_land<FWD, false, 0>(v[0], v[1], v[2], v[3]);
+  hook_at<P5>(hook);
+  bf4_land<FWD, false, 1>(v[4], v[5], v[6], v[7]);
+  hook_at<P6>(hook);
+  bf4_land<FWD, true, 2>(v[8], v[9], v[10], v[11]);
+  bf4_land<FWD, false, 3>(v[12], v[13], v[14], v[15]);
+}
 #define CLFA_DFT16_H(FWD, v, hook, M) \
   dft16_hp<FWD, decltype(hook), M.p[0], M.p[1], M.p[2], M.p[3], M.p[4], M.p[5], M.p[6], M.p[7]>(v, hook)
 
@@ -519,7 +572,8 @@ template <int RB, bool INV = false> __device__ __forceinline__ void res_fetch_st
 }
 // ---- phase 2: one row block ---------------------------------------------------------------------
 // v[e] = Z[16 rb + t][c + 16 e] -> X[16 rb + c + 256 (t + 16 e)] left in v[e] (lane = row c, k2 = t + 16 e)
-template <bool FWD, int PROBE = 0, class H = HookNone>
+// LAND: the results go straight into the landing registers (dft16_hp_land) instead of v
+template <bool FWD, int PROBE = 0, bool LAND = false, class H = HookNone>
 __device__ __forceinline__ void res_row_block(cpx (&v)[16], const ResLane &L, const H &hook = H()) {
   if constexpr (!(PROBE & kProbeNoMath)) CLFA_DFT16_H(FWD, v, hook, kMapRowC);
   if constexpr (!(PROBE & kProbeNoXchg)) {
@@ -550,7 +604,8 @@ __device__ __forceinline__ void res_row_block(cpx (&v)[16], const ResLane &L, co
       if (i == 7) hook_at<9>(hook);
     }
   }
-  CLFA_DFT16_H(FWD, v, hook, kMapRowD);
+  if constexpr (LAND) dft16_hp_land<FWD, H, kMapRowD.p[0], kMapRowD.p[1], kMapRowD.p[2], kMapRowD.p[3], kMapRowD.p[4], kMapRowD.p[5], kMapRowD.p[6], kMapRowD.p[7]>(v, hook);
+  else CLFA_DFT16_H(FWD, v, hook, kMapRowD);
 }
 
 // phase 1, one column block: wait for its data (N younger asm loads), take it out of its landing zone
@@ -1185,12 +1240,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
         res_load_land(xn + 16, L.voff);
       }
     } else {
+    constexpr bool kLand = PROBE == 0;   // row blocks leave their results in the landing registers themselves (dft16_hp_land)
     {
       const ResLane L = lane();
       if constexpr (!(PROBE & kProbeNoSlot)) res_wait_vm<0>();
       res_land_fetch(v);
-      res_row_block<FWD, PROBE>(v, L);
-      res_stage(v);
+      res_row_block<FWD, PROBE, kLand>(v, L);
+      if constexpr (!kLand) res_stage(v);
     }
     int rb_prev = kLdsBlk;
 #pragma unroll 1
@@ -1211,11 +1267,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
         }
       }
       if constexpr (!(PROBE & kProbeNoStore)) {
-        res_row_block<FWD, PROBE>(v, L, HookStore{res_rsrc(y + ((rb_prev + rot) & 15) * 16), L.voff, so});
+        res_row_block<FWD, PROBE, kLand>(v, L, HookStore{res_rsrc(y + ((rb_prev + rot) & 15) * 16), L.voff, so});
       } else {
         res_row_block<FWD, PROBE>(v, L);
       }
-      res_stage(v);
+      if constexpr (!kLand) res_stage(v);
       rb_prev = rb;
     }
     {
