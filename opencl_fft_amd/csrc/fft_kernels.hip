@@ -189,7 +189,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   // twiddles in LDS: half table W_n^k (k < n/2); n = 8192: the lane-addressed tables of LaneTab13
   // (fft_device.hpp: 1280 entries, which keeps the block at 78 KiB so that two workgroups share a CU)
   constexpr bool TWO = kLdsTwoLevel(LOGN);
-  constexpr int NTAB = TWO ? kLane13Lds : G::HALF;
+  constexpr int NTAB = TWO ? kLaneLds : G::HALF;
   __shared__ cpx s_tab[NTAB];
   __shared__ cpx s_x[FPW * G::PADN];
 
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     const long b = g * FPW + f;
     lds_fft_load<LOGN, MODE, FWD>(v, data + (b < batch ? b : batch - 1) * (long)N, t);
   }
-  for (int i = tid; i < (TWO ? NTAB : N / 2); i += WG) s_tab[i] = tab_g[i];
+  for (int i = tid; i < (TWO ? kLane13Lds : N / 2); i += WG) s_tab[TWO ? lane_lds_index(i) : i] = tab_g[i];
   cpx *xb = s_x + f * G::PADN;
   // the lane's own twiddle constants: W_8192^t (n = 8192); W_16384^t, ^(2 t), ^(3 t) (n = 16384)
   cpx wl[LOGN == 14 ? 3 : 1];
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     int t = t_invariant;
     asm volatile("" : "+v"(t));
     const auto tab2 = [&]() {
-      if constexpr (LOGN == 14) return LaneTab14{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl[0], wl[1], wl[2]};
-      else return LaneTab13{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl[0]};
+      if constexpr (LOGN == 14) return LaneTab14{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl[0], wl[1], wl[2]};
+      else return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl[0]};
     }();
     const long b = g * FPW + f;
     const bool active = b < batch;
@@ -504,11 +504,11 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
                                                                     const cpx *__restrict__ w2_g, long batch, long out_off) {
   constexpr int LOGN = LOGC, E = 1 << LOGE, M = 1 << LOGC, T = M / E, R = 1 << pass_rem_logr(LOGC, LOGE);
   constexpr bool LANE = kLdsTwoLevel(LOGC);   // lane-addressed tables (8192 / 16384 points) or the half table W_M^k
-  constexpr int NTAB = LANE ? kLane13Lds : M / 2;
+  constexpr int NTAB = LANE ? kLaneLds : M / 2;
   __shared__ cpx s_tab[NTAB];
   __shared__ cpx s_x[lds_padded_size(M)];
   const int tid = threadIdx.x;
-  for (int i = tid; i < NTAB; i += T) s_tab[i] = tab_g[i];
+  for (int i = tid; i < (LANE ? kLane13Lds : M / 2); i += T) s_tab[LANE ? lane_lds_index(i) : i] = tab_g[i];
   // lane constants kept across the batch loop: W_M^tid and W_4M^tid only (4 VGPRs; the kernel runs under the 128-VGPR
   // cap) — W_M^(2 tid), ^(3 tid) and W_2M^tid are their products
   const cpx wl0 = LANE ? tab_g[kLane13Lds + tid] : mk(1.f, 0.f);
@@ -522,9 +522,9 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
     const auto tab = [&]() {
       if constexpr (LOGC == 14) {
         const cpx wl1 = cmul(wl0, wl0);
-        return LaneTab14{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0, wl1, cmul(wl0, wl1)};
+        return LaneTab14{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0, wl1, cmul(wl0, wl1)};
       } else if constexpr (LOGC == 13) {
-        return LaneTab13{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0};
+        return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0};
       } else {
         return static_cast<const cpx *>(s_tab);
       }
@@ -637,10 +637,10 @@ __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_cfft_2x(cpx *__restrict
                                                                  long batch, long out_off) {
   using G = LdsGeom<LOGC>;
   constexpr int LOGN = LOGC, LOGE = 4, E = 16, M = 1 << LOGC, T = M / E;
-  __shared__ cpx s_tab[kLane13Lds];
+  __shared__ cpx s_tab[kLaneLds];
   __shared__ cpx s_x[G::PADN];
   const int tid = threadIdx.x;
-  for (int i = tid; i < kLane13Lds; i += T) s_tab[i] = tab_g[i];
+  for (int i = tid; i < kLane13Lds; i += T) s_tab[lane_lds_index(i)] = tab_g[i];
   const cpx wl0 = tab_g[kLane13Lds + tid];                                     // W_M^tid
   const cpx h0 = tab_g[(LOGC == 14 ? kLane14Size : kLane13Size) + tid];        // W_2M^tid (forward sign, like every table)
   cpx *xb = s_x;
@@ -652,9 +652,9 @@ __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_cfft_2x(cpx *__restrict
     const auto tab = [&]() {
       if constexpr (LOGC == 14) {
         const cpx wl1 = cmul(wl0, wl0);
-        return LaneTab14{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0, wl1, cmul(wl0, wl1)};
+        return LaneTab14{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0, wl1, cmul(wl0, wl1)};
       } else {
-        return LaneTab13{s_tab + 16 * (t & 15), s_tab + 256 + (t & 255), wl0};
+        return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0};
       }
     }();
     cpx *x = data + b * (long)(2 * M);

@@ -42,7 +42,9 @@
 //
 // Global accesses are buffer_load/store_dwordx2 ... offen nt with the row offsets e * 32 KiB in
 // SGPRs: one instruction per access, no address arithmetic.  Both LDS exchanges write 8 x b128 and
-// read 16 x b64, conflict-free (layouts below).  The four-step twiddles W_N^(n2 (t + 16 e)) =
+// read 16 x SINGLE b64 (CLFA_DS_SINGLE below: paired into ds_read2_b64, as hipcc would, every read is a 2-way bank
+// conflict), conflict-free under MI355X_MICROARCH.md's lane-group rules (layouts below; rocprofv3 round 5:
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.29 -> 0.05, what is left is the spill deposit).  The four-step twiddles W_N^(n2 (t + 16 e)) =
 // b * s^e come from one two-level lookup (b), four exact table values s, s^2, s^4, s^8 and a
 // product tree (15 complex multiplies for 16 values); the forward 1/N rides on the table of b.
 //
@@ -78,7 +80,11 @@ constexpr int kN = 65536;
 constexpr int kLdsBlk = 3, kGlbBlk = 1, kVgprBlk = 4, kAgprBlk = 8;
 constexpr int kVgprFirst = kLdsBlk + kGlbBlk, kAgprFirst = kVgprFirst + kVgprBlk;
 static_assert(kAgprFirst + kAgprBlk == 16, "16 row blocks");
-constexpr int kSpillStride = 400;   // bytes per lane: 3 x 128 + 16 (36 dwords mod 64: b64 / b128 conflict-free)
+// bytes per lane: 3 x 128 + 16 = 100 dwords.  The b128 reads of phase 2 (16-lane groups over 64 banks: 36 l mod 64) are
+// conflict-free; the three ds_write_b64 of a deposit (16 contiguous lanes over 32 banks: 4 l mod 32) pair lanes l, l + 8 —
+// 8 LDS-array cycles against the 6 the instruction takes to hand its operands over anyway: 2 cycles per write.  A stride
+// that serves both (2 x odd dwords) would turn the reads into 16 x b64 for nothing measurable.
+constexpr int kSpillStride = 400;
 constexpr int kXA = 258;            // phase-1 exchange: element (column c, position p) at c * 258 + p
 constexpr int kXB = 290;            // phase-2 exchange: element (row r, position p) at r * 290 + p + 2 (p / 16)
 constexpr int kXSize = 16 * kXB;
@@ -263,6 +269,8 @@ __device__ __forceinline__ f4 pack2(cpx a, cpx b) { return f4{a.x, a.y, b.x, b.y
 // data, profiles/res16_probe_r02.txt).  So a column block's code has 16 hook points, ~20 instructions
 // apart, and each issues ONE load of the block two ahead.  so[e] = e * 32 KiB, pinned in SGPRs.
 template <int K> using ic = std::integral_constant<int, K>;
+template <int... I, class F> __device__ __forceinline__ void static_for_(std::integer_sequence<int, I...>, F &&f) { (f(ic<I>()), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_(std::make_integer_sequence<int, N>(), f); }
 struct HookNone {
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {}
 };
@@ -274,12 +282,15 @@ template <int CB, bool KEEP = false> struct HookAcc {   // -> AGPR columns CB, C
   const int (&so)[16];
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
     constexpr int lo = 32 * (K & 7) + 2 * (K < 8 ? CB : CB + 1);
-    if constexpr (K == 0)   // the descriptor's SGPRs may be fresh from SALU: 5 wait states before VMEM reads them
-      asm volatile("s_nop 4" ::"s"(r));
-    if constexpr (KEEP)
-      asm volatile("buffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen" ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
-    else
-      asm volatile("buffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory");
+    // K == 0: the descriptor's SGPRs may be fresh from SALU — 5 wait states before VMEM reads them, in the SAME asm
+    // statement as the load (between two statements hipcc may re-materialise the descriptor)
+#define CLFA_LD_ACC(PRE, POL) \
+  asm volatile(PRE "buffer_load_dwordx2 a[%c2:%c3], %0, %1, %4 offen" POL ::"v"(voff), "s"(r), "n"(lo), "n"(lo + 1), "s"(so[K]) : "memory")
+    if constexpr (K == 0 && KEEP) CLFA_LD_ACC("s_nop 4\n\t", "");
+    else if constexpr (K == 0) CLFA_LD_ACC("s_nop 4\n\t", CLFA_LDNT);
+    else if constexpr (KEEP) CLFA_LD_ACC("", "");
+    else CLFA_LD_ACC("", CLFA_LDNT);
+#undef CLFA_LD_ACC
   }
 };
 template <bool KEEP = false> struct HookLandT {   // -> landing registers v[224:255]
@@ -287,11 +298,13 @@ template <bool KEEP = false> struct HookLandT {   // -> landing registers v[224:
   int voff;
   const int (&so)[16];
   template <int K> __device__ __forceinline__ void operator()(ic<K>) const {
-    if constexpr (K == 0) asm volatile("s_nop 4" ::"s"(r));
-    if constexpr (KEEP)
-      asm volatile("buffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen" ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
-    else
-      asm volatile("buffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen" CLFA_LDNT ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory");
+#define CLFA_LD_LAND(PRE, POL) \
+  asm volatile(PRE "buffer_load_dwordx2 v[%c2:%c3], %0, %1, %4 offen" POL ::"v"(voff), "s"(r), "n"(224 + 2 * K), "n"(225 + 2 * K), "s"(so[K]) : "memory")
+    if constexpr (K == 0 && KEEP) CLFA_LD_LAND("s_nop 4\n\t", "");
+    else if constexpr (K == 0) CLFA_LD_LAND("s_nop 4\n\t", CLFA_LDNT);
+    else if constexpr (KEEP) CLFA_LD_LAND("", "");
+    else CLFA_LD_LAND("", CLFA_LDNT);
+#undef CLFA_LD_LAND
   }
 };
 using HookLand = HookLandT<false>;
@@ -356,8 +369,12 @@ template <int G, class H> __device__ __forceinline__ void hook_at(const H &hook)
   }
 }
 // dft16 of fft_device.hpp with eight hook points
-template <bool FWD, class H, int P0, int P1, int P2, int P3, int P4, int P5, int P6, int P7>
-__device__ __forceinline__ void dft16_hp(cpx (&v)[16], const H &hook) {
+struct NoTail {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `tail` runs after hook point P6, ahead of the last two butterflies (res_col_block issues its table lookups there)
+template <bool FWD, class H, int P0, int P1, int P2, int P3, int P4, int P5, int P6, int P7, class T = NoTail>
+__device__ __forceinline__ void dft16_hp(cpx (&v)[16], const H &hook, const T &tail = T()) {
   bf4<FWD>(v[0], v[4], v[8], v[12]);
   hook_at<P0>(hook);
   bf4<FWD>(v[1], v[5], v[9], v[13]);
@@ -378,6 +395,7 @@ __device__ __forceinline__ void dft16_hp(cpx (&v)[16], const H &hook) {
   hook_at<P5>(hook);
   bf4<FWD>(x[4], x[5], x[6], x[7]);
   hook_at<P6>(hook);
+  tail();
   bf4_rot2<FWD>(x[8], x[9], x[10], x[11]);
   hook_at<P7>(hook);
   bf4<FWD>(x[12], x[13], x[14], x[15]);
@@ -441,7 +459,17 @@ __device__ __forceinline__ void dft16_hp_land(cpx (&v)[16], const H &hook) {
 }
 #define CLFA_DFT16_H(FWD, v, hook, M) \
   dft16_hp<FWD, decltype(hook), M.p[0], M.p[1], M.p[2], M.p[3], M.p[4], M.p[5], M.p[6], M.p[7]>(v, hook)
+#define CLFA_DFT16_HT(FWD, v, hook, M, tail) \
+  dft16_hp<FWD, decltype(hook), M.p[0], M.p[1], M.p[2], M.p[3], M.p[4], M.p[5], M.p[6], M.p[7], decltype(tail)>(v, hook, tail)
 
+// build switches of the second passes (A/B; the library's choice is the default)
+#ifndef CLFA_TW_AHEAD
+#define CLFA_TW_AHEAD 1     // the second pass's twiddle rows are read one group (two b128) ahead of their use: the hook
+#endif                      // points are scheduling fences, and a read issued right before its use costs one wave per
+                            // SIMD the whole LDS latency, three times per block
+#ifndef CLFA_FS_AHEAD
+#define CLFA_FS_AHEAD 1     // the four-step twiddle lookups are issued before the second pass's last butterflies
+#endif
 struct ResLane {
   int c, t;          // lane = c + 16 t
   int voff;          // byte offset of the lane inside a column / row block of global memory
@@ -453,6 +481,41 @@ struct ResLane {
   char *spill;       // lane-private LDS rows
   int slot_off;      // byte offset of the lane in one [cb] row of the workgroup's global slot
 };
+
+// second pass of a block: inputs times W_256^(t j) (row t of the table); hooks H0 .. H0 + 3 after the four groups
+template <bool FWD, int H0, bool AHEAD, class H> __device__ __forceinline__ void res_tw_rows(cpx (&v)[16], const ResLane &L, const H &hook) {
+  const f4 *pt = reinterpret_cast<const f4 *>(L.tw_row);
+  if constexpr (AHEAD) {
+    f4 wa = pt[0], wb = pt[1], na = pt[2], nb = pt[3];
+    static_for<4>([&](auto G) {
+      constexpr int g = decltype(G)::value;
+      if constexpr (g == 0) v[1] = cmulc<!FWD>(v[1], mk(wa.z, wa.w));
+      else cmulc2<!FWD>(v[4 * g], v[4 * g + 1], v[4 * g], mk(wa.x, wa.y), v[4 * g + 1], mk(wa.z, wa.w));
+      cmulc2<!FWD>(v[4 * g + 2], v[4 * g + 3], v[4 * g + 2], mk(wb.x, wb.y), v[4 * g + 3], mk(wb.z, wb.w));
+      wa = na;
+      wb = nb;
+      if constexpr (g < 2) {   // the group after next, issued ahead of the fence
+        na = pt[2 * g + 4];
+        nb = pt[2 * g + 5];
+      }
+      hook_at<H0 + g>(hook);
+    });
+  } else {
+    {
+      const f4 w = pt[0];
+      v[1] = cmulc<!FWD>(v[1], mk(w.z, w.w));
+    }
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+      const f4 w = pt[i];
+      cmulc2<!FWD>(v[2 * i], v[2 * i + 1], v[2 * i], mk(w.x, w.y), v[2 * i + 1], mk(w.z, w.w));
+      if (i == 1) hook_at<H0>(hook);
+      if (i == 3) hook_at<H0 + 1>(hook);
+      if (i == 5) hook_at<H0 + 2>(hook);
+      if (i == 7) hook_at<H0 + 3>(hook);
+    }
+  }
+}
 
 // ---- phase 1: one column block ------------------------------------------------------------------
 // v: rows t + 16 e of column n2 = 16 cb + c (already loaded) -> o[e] = Z[t + 16 e][n2]
@@ -473,29 +536,28 @@ __device__ __forceinline__ void res_col_block(cpx (&v)[16], const ResLane &L, in
   }
   if constexpr (PROBE & kProbeNoMath) return;
   // second pass: inputs times W_256^(t j) (row t of the table), then the butterflies
-  {
-    const f4 *pt = reinterpret_cast<const f4 *>(L.tw_row);
-    {
-      const f4 w = pt[0];
-      v[1] = cmulc<!FWD>(v[1], mk(w.z, w.w));
-    }
-#pragma unroll
-    for (int i = 1; i < 8; i++) {
-      const f4 w = pt[i];
-      cmulc2<!FWD>(v[2 * i], v[2 * i + 1], v[2 * i], mk(w.x, w.y), v[2 * i + 1], mk(w.z, w.w));
-      if (i == 1) hook_at<4>(hook);
-      if (i == 3) hook_at<5>(hook);
-      if (i == 5) hook_at<6>(hook);
-      if (i == 7) hook_at<7>(hook);
-    }
-  }
-  CLFA_DFT16_H(FWD, v, hook, kMapColB);
+  res_tw_rows<FWD, 4, CLFA_TW_AHEAD>(v, L, hook);
   // four-step twiddles W_N^(n2 (t + 16 e)) = b * s^e,  b = W_N^(n2 t),  s = W_4096^n2
   const int n2 = cb * 16 + L.c;
   const int m = n2 * L.t;   // < 4096
-  const cpx b = cmul(s_tab[kTabLo + (m & 255)], s_tab[kTabHi + (m >> 8)]);
   const cpx *ps = s_tab + kTabS + n2;
-  const cpx s1 = ps[0], s2 = ps[256], s4 = ps[512], s8 = ps[768];
+  cpx blo, bhi, s1, s2, s4, s8;
+  auto lookups = [&]() {
+    blo = s_tab[kTabLo + (m & 255)], bhi = s_tab[kTabHi + (m >> 8)];
+    s1 = ps[0], s2 = ps[256], s4 = ps[512], s8 = ps[768];
+  };
+  if constexpr (CLFA_FS_AHEAD) {
+    // the six reads go out ahead of the pass's last two butterflies (a fence keeps them there)
+    auto tail = [&]() {
+      lookups();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    CLFA_DFT16_HT(FWD, v, hook, kMapColB, tail);
+  } else {
+    CLFA_DFT16_H(FWD, v, hook, kMapColB);
+    lookups();
+  }
+  const cpx b = cmul(blo, bhi);
   // product tree in halves of four (T_r = b s^r, U_r = T_r s^8), two products per statement
   cpx T[4], U[4];
   T[0] = b;
@@ -573,7 +635,8 @@ template <int RB, bool INV = false> __device__ __forceinline__ void res_fetch_st
 // ---- phase 2: one row block ---------------------------------------------------------------------
 // v[e] = Z[16 rb + t][c + 16 e] -> X[16 rb + c + 256 (t + 16 e)] left in v[e] (lane = row c, k2 = t + 16 e)
 // LAND: the results go straight into the landing registers (dft16_hp_land) instead of v
-template <bool FWD, int PROBE = 0, bool LAND = false, class H = HookNone>
+// TWA: the twiddle rows read a group ahead (CLFA_TW_AHEAD; the packed real forward kernel has no registers for it)
+template <bool FWD, int PROBE = 0, bool LAND = false, bool TWA = true, class H = HookNone>
 __device__ __forceinline__ void res_row_block(cpx (&v)[16], const ResLane &L, const H &hook = H()) {
   if constexpr (!(PROBE & kProbeNoMath)) CLFA_DFT16_H(FWD, v, hook, kMapRowC);
   if constexpr (!(PROBE & kProbeNoXchg)) {
@@ -588,22 +651,7 @@ __device__ __forceinline__ void res_row_block(cpx (&v)[16], const ResLane &L, co
   for (int e = 0; e < 16; e++) v[e] = L.xb_r[18 * e];
   }
   if constexpr (PROBE & kProbeNoMath) return;
-  {
-    const f4 *pt = reinterpret_cast<const f4 *>(L.tw_row);
-    {
-      const f4 w = pt[0];
-      v[1] = cmulc<!FWD>(v[1], mk(w.z, w.w));
-    }
-#pragma unroll
-    for (int i = 1; i < 8; i++) {
-      const f4 w = pt[i];
-      cmulc2<!FWD>(v[2 * i], v[2 * i + 1], v[2 * i], mk(w.x, w.y), v[2 * i + 1], mk(w.z, w.w));
-      if (i == 1) hook_at<6>(hook);
-      if (i == 3) hook_at<7>(hook);
-      if (i == 5) hook_at<8>(hook);
-      if (i == 7) hook_at<9>(hook);
-    }
-  }
+  res_tw_rows<FWD, 6, CLFA_TW_AHEAD && TWA>(v, L, hook);
   if constexpr (LAND) dft16_hp_land<FWD, H, kMapRowD.p[0], kMapRowD.p[1], kMapRowD.p[2], kMapRowD.p[3], kMapRowD.p[4], kMapRowD.p[5], kMapRowD.p[6], kMapRowD.p[7]>(v, hook);
   else CLFA_DFT16_H(FWD, v, hook, kMapRowD);
 }
@@ -659,8 +707,6 @@ constexpr int kTabSizeR = kTabSize + 272;
 constexpr int kParkAcc = 224;        // B' results parked in a[224:255] (keep row 15's registers, fetched first)
 constexpr int kSlotAcc = 192;        // the slot's row block lands in a[192:223] (keep row 14's, free after pair 1)
 
-template <int... I, class F> __device__ __forceinline__ void static_for_(std::integer_sequence<int, I...>, F &&f) { (f(ic<I>()), ...); }
-template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_(std::make_integer_sequence<int, N>(), f); }
 
 template <int BASE> __device__ __forceinline__ void acc_fetch_flat(cpx (&v)[16]) {
   static_for<16>([&](auto E) { v[decltype(E)::value] = mk(acc_read<BASE + 2 * decltype(E)::value>(), acc_read<BASE + 2 * decltype(E)::value + 1>()); });
@@ -707,9 +753,10 @@ __device__ __forceinline__ void res_store_land(__amdgpu_buffer_rsrc_t r, int vof
 // a block's 16 stores out of compiler registers, with the pinned row offsets (the builtin of res_store() would make
 // hipcc hold a second copy of the 15 offsets in SGPRs, which this variant of the kernel does not have)
 __device__ __forceinline__ void res_store_so(const cpx (&v)[16], __amdgpu_buffer_rsrc_t r, int voff, const int (&so)[16]) {
-  asm volatile("s_nop 4" ::"s"(r) : "memory");   // (the descriptor's SGPRs may be fresh from SALU)
+  // (the descriptor's SGPRs may be fresh from SALU: the wait states sit in the first store's own statement)
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen" CLFA_STNT ::"v"(v[0]), "v"(voff), "s"(r), "s"(so[0]) : "memory");
 #pragma unroll
-  for (int e = 0; e < 16; e++)
+  for (int e = 1; e < 16; e++)
     asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" CLFA_STNT ::"v"(v[e]), "v"(voff), "s"(r), "s"(so[e]) : "memory");
 }
 // W_2M^i of the lane's register e: base * W_32^e
@@ -925,8 +972,20 @@ __device__ __forceinline__ void res_probe_grid_sync(unsigned long long *dbg, uns
 // R2C: packed real transforms of size 2 kN, forward — the same transform with the reference's pair map inside phase 2
 // (above); w2_g = the plan's pair twiddles W_2M^i (cl_fft.cpp:233-238), M entries
 // C2R: ... inverse — the pair map inside phase 1 (above)
+// CLFA_DS_SINGLE: hipcc's load / store optimiser pairs the exchanges' sixteen ds_read_b64 into eight ds_read2_b64, which the
+// LDS serves per 16 contiguous lanes over 32 banks at half the rate (MI355X_MICROARCH.md, LDS table): in the layouts above —
+// made for the single reads, 2 x 32 lanes over 64 banks — every access is then a 2-way conflict, four times the LDS cycles
+// (rocprofv3 round 4: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.29).  The pass is off for this kernel.
+#ifndef CLFA_DS_SINGLE
+#define CLFA_DS_SINGLE 1
+#endif
+#if CLFA_DS_SINGLE && defined(__HIP_DEVICE_COMPILE__)
+#define CLFA_RES16_TARGET __attribute__((target("no-load-store-opt")))
+#else
+#define CLFA_RES16_TARGET
+#endif
 template <bool FWD, bool SCALE, int PROBE = 0, bool R2C = false, bool C2R = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_fft_res16(const cpx *data, cpx *out, cpx *__restrict__ slots,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) CLFA_RES16_TARGET void k_fft_res16(const cpx *data, cpx *out, cpx *__restrict__ slots,
                                                    const cpx *__restrict__ tabs_g, long batch,
                                                    unsigned long long *__restrict__ dbg = nullptr,
                                                    const cpx *__restrict__ w2_g = nullptr) {
@@ -1196,8 +1255,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
           // ... with the stores of A'_(q-1) (landing registers) riding along
           const __amdgpu_buffer_rsrc_t ra =
               __builtin_amdgcn_make_buffer_rsrc(y + (q - 1) * 16, 0, live, 0x00020000);
-          if (q == 2) res_row_block<FWD, PROBE>(v, L, Hook2<HookStore, HookSlotAcc>{HookStore{ra, L.voff, so}, HookSlotAcc{slot, L.slot_off, so}});
-          else res_row_block<FWD, PROBE>(v, L, HookStore{ra, L.voff, so});
+          if (q == 2) res_row_block<FWD, PROBE, false, false>(v, L, Hook2<HookStore, HookSlotAcc>{HookStore{ra, L.voff, so}, HookSlotAcc{slot, L.slot_off, so}});
+          else res_row_block<FWD, PROBE, false, false>(v, L, HookStore{ra, L.voff, so});
           base = cmul(s_tab[kTabPair + 16 * q + L.c], s_tab[kTabPair + 256 + L.t]);
           if (q == 0) {
             res_pair_self_row<true>(v, L.c, L.t, base, s_c0);
@@ -1221,7 +1280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(224))) void k_f
           // ... with the stores of B'_(q-1) (parked in the accumulation registers, finished by the patch above)
           const __amdgpu_buffer_rsrc_t rb =
               __builtin_amdgcn_make_buffer_rsrc(y + (16 - q) * 16, 0, live, 0x00020000);
-          res_row_block<FWD, PROBE>(v, L, HookStoreAcc{rb, L.voff, so});
+          res_row_block<FWD, PROBE, false, false>(v, L, HookStoreAcc{rb, L.voff, so});
           if (L.c != 0) res_pair_map(v, base);
           if (q == 7) {
             const cpx bm = cmul(s_tab[kTabPair + 128], s_tab[kTabPair + 256 + 15 - L.t]);

@@ -16,6 +16,19 @@ constexpr int kLdsMaxLog = 13;
 // kLane13Lds entries live in LDS
 constexpr bool kLdsTwoLevel(int logn) { return logn >= 13; }
 constexpr int kLane13Lds = 1280, kLane13Size = 1792;
+// ... in LDS the rows of the 16 x 16 part are kRow16Stride entries apart: the sixteen lanes of a ds_read_b128 group read
+// sixteen DIFFERENT rows (row = tid & 15); 16 entries = 32 dwords apart they would fall on two groups of four banks (an
+// 8-way conflict, 32 LDS cycles per read — rocprofv3 round 4: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.41-0.46 for
+// config 3's kernel); 18 entries = 36 dwords apart they cover the 64 banks exactly once (MI355X_MICROARCH.md, LDS table)
+#ifndef CLFA_ROW16_STRIDE
+#define CLFA_ROW16_STRIDE 18
+#endif
+constexpr int kRow16Stride = CLFA_ROW16_STRIDE;
+static_assert(kRow16Stride >= 16 && kRow16Stride % 2 == 0, "rows stay 16-byte aligned");
+constexpr int kRow16Lds = 16 * kRow16Stride;            // the s256 part follows
+constexpr int kLaneLds = kRow16Lds + (kLane13Lds - 256);   // entries of the LDS copy
+// LDS index of entry i < kLane13Lds of the global table
+__host__ __device__ constexpr int lane_lds_index(int i) { return i < 256 ? (i >> 4) * kRow16Stride + (i & 15) : i + (kRow16Lds - 256); }
 // the 16384-point chains of k_rfft_2x<14> (packed real size 65536: 1024 lanes, passes 16 x 16 x 16 x 4, fft_device.hpp
 // LaneTab14): the same LDS part, then [W_16384^t | W_16384^(2 t) | W_16384^(3 t)], t < 1024
 constexpr int kLds14Log = 14, kLane14Size = kLane13Lds + 3 * 1024;
