@@ -88,26 +88,49 @@ def traffic_from_profiles(key):
         return None, None
 
 
-def reference_timing():
-    """The UNMODIFIED reference (Clcfft::transform, cl_fft.cpp:153-161: one N = 65536 transform per call, 17 launches and two
-    PCIe copies each) timed on this machine's OpenCL device by oracle/_ref/ref_driver (built from the reference's sources in
-    place by `make -C oracle ref`; the binary travels with the repository, the sources do not) — live when the binary and
-    an OpenCL device are there, else the measurement committed with the golden vectors.  The reference has no CPU path of
-    its own: its "CPU path" would be these same kernels on a CPU OpenCL device, and no CPU ICD exists on these machines."""
+def under_profiler():
+    """rocprofv3 preloads its tool library into this process AND into every child: the reference's OpenCL kernels would land in
+    the same trace directories (and its timing would carry the profiler's overhead), so the reference legs are skipped there"""
+    return "rocprofiler" in os.environ.get("LD_PRELOAD", "") or "ROCPROF_OUTPUT_PATH" in os.environ or "ROCPROFILER_LIBRARY_CTOR" in os.environ
+
+
+def reference_timing(kind, pci_bus=None):
+    """The UNMODIFIED reference timed on this machine's OpenCL device by oracle/_ref/ref_driver (built from the reference's
+    sources in place by `make -C oracle ref`; the binary travels with the repository, the sources do not) — live when the
+    binary and an OpenCL device are there; the c2c leg falls back to the measurement committed with the golden vectors.
+      cfft : Clcfft::transform N = 65536 (cl_fft.cpp:153-161: one transform per call, 17 launches, two PCIe copies)
+      rfft : Clrfft::transform size 16384, forward / inverse alternating (cl_fft.cpp:267-296)
+      pconv: Clpconv::convolution(out, in), pts 1024, 94 partitions, ONE instance per object as the reference has it
+             (cl_conv.cpp:393-458: 26 launches and two copies per block) — BASELINE configs[3] is 256 such instances
+    The reference has no CPU path of its own: its "CPU path" would be these same kernels on a CPU OpenCL device, and no CPU
+    ICD exists on these machines.  The OpenCL device is picked by the PCI bus of the GPU this rank runs on (OpenCL's
+    enumeration need not follow HIP's ordinals)."""
     import numpy as np
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    what = "Clcfft::transform N=65536, one transform per call, PCIe copies included"
-    if os.path.exists(exe):
+    what = {"cfft": "Clcfft::transform N=65536, one transform per call, PCIe copies included",
+            "rfft": "Clrfft::transform size=16384, r2c / c2r alternating, one transform per call, PCIe copies included",
+            "pconv": "Clpconv::convolution(out, in) pts=1024, 94 partitions, ONE instance, per block, PCIe copies included"}[kind]
+    args = {"cfft": ["time"], "rfft": ["time-rfft", "16384"], "pconv": ["time-pconv", "1024", "96256", "300"]}[kind]
+    index = str(int(os.environ.get("LOCAL_RANK", "0")))
+    for devspec in (["pci:%02x" % pci_bus] if pci_bus is not None else []) + [index]:   # (the index only if the bus finds nothing)
+        if not os.path.exists(exe) or under_profiler():
+            break
         try:
-            out = subprocess.run([exe, "/tmp", str(int(os.environ.get("LOCAL_RANK", "0"))), "time"], stdout=subprocess.PIPE,
-                                 stderr=subprocess.DEVNULL, timeout=120)
+            out = subprocess.run([exe, "/tmp", devspec] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
             f = out.stdout.decode().split()
             if out.returncode == 0 and len(f) >= 3:
-                return {"value": float(f[1]), "unit": "Gsamples/s", "us_per_transform": float(f[0]), "kind": "reference",
-                        "what": what, "source": "measured in this run: oracle/_ref/ref_driver time (%d transforms, OpenCL device %s)"
-                        % (int(f[2]), " ".join(f[3:]) or "?")}
+                r = {"value": float(f[1]), "unit": "Gsamples/s", "kind": "reference", "what": what,
+                     "source": "measured in this run: oracle/_ref/ref_driver %s (%d calls, OpenCL device %s, selected by %s)"
+                     % (" ".join(args), int(f[2]), " ".join(f[3:]) or "?", devspec)}
+                r["us_per_block" if kind == "pconv" else "us_per_transform"] = float(f[0])
+                if kind == "pconv":   # what 256 channels cost the reference: 256 objects called one after the other
+                    r["us_per_block_256_instances"] = 256 * float(f[0])
+                    r["realtime_ratio_256_instances"] = (1024 / 48000.0) / (256 * float(f[0]) * 1e-6)
+                return r
         except (OSError, subprocess.SubprocessError, ValueError):
             pass
+    if kind != "cfft":
+        return None
     try:
         t_ref = np.fromfile(os.path.join(ROOT, "tests", "golden", "ref", "timing_ref_cfft65536.bin"), dtype=np.float64)
         return {"value": float(t_ref[1]), "unit": "Gsamples/s", "us_per_transform": float(t_ref[0]), "kind": "reference",
@@ -524,8 +547,16 @@ def main():
             rec["config"]["per_rank"] = per_rank
         if oop is not None:
             rec["config"]["out_of_place"] = oop
-        if a.workload == "c2c":
-            rec["reference_opencl_same_gpu"] = reference_timing()
+        # the unmodified reference on the same GPU (child processes, after every timed region)
+        try:
+            pci_bus = int(torch.cuda.get_device_properties(local).pci_bus_id)
+        except (AttributeError, TypeError, ValueError):
+            pci_bus = None
+        rec["reference_opencl_same_gpu"] = reference_timing({"c2c": "cfft", "rfft": "rfft", "pconv": "pconv"}[a.workload], pci_bus)
+        if others is not None:
+            for leg in ("rfft", "pconv"):
+                if leg in others:
+                    others[leg]["reference_opencl_same_gpu"] = reference_timing(leg, pci_bus)
         if cold is not None:
             # the contract's W + K launches read cold (before the self-check): inside the chip's start-up clock ramp
             rec["ms_per_step_cold"] = cold["ms_per_step"]

@@ -70,6 +70,9 @@ template <bool REAL> struct FftOp : csnd::Plugin<1, 3> {
       return csound->init_error(msg);
     }
     work.allocate(csound, REAL ? np2 : 2 * np2);
+    // the one array every k-cycle's transform() runs on, for the life of the instance: pinned, so the transform needs no
+    // staging copies (a refusal is not an error: the calls then copy as the reference's do)
+    plan->pin_host(work.data(), sizeof(float) * (REAL ? np2 : 2 * np2));
     return OK;
   }
 

@@ -25,8 +25,10 @@ class Clcfft {
   // The reference's device members a subclass may touch (cl_fft.h:35-37), as HIP objects (cl_compat.h: cl_mem = device
   // pointer, cl_command_queue = hipStream_t; clEnqueueWriteBuffer / clEnqueueReadBuffer / clFinish work on them):
   // w = N twiddles, b = N bit reversals (cl_fft.cpp:86-104), data1 / data2 = N complex numbers each, commands = the
-  // object's stream.  They exist for the reference's range of sizes (N <= 65536; NULL above).  fft() (cl_fft.h:44,
-  // cl_fft.cpp:138-151) transforms data1 -> data2 on that stream and, like the reference, only enqueues.
+  // object's stream.  They exist for the reference's range of sizes (N <= 65536; NULL above; a failure to create them is
+  // a setup error, get_error()).  fft() (cl_fft.h:44, cl_fft.cpp:138-151) transforms data1 -> data2 on that stream and,
+  // like the reference, only enqueues; on a Clrfft it is the complex transform of the N = size / 2 points alone, as in the
+  // reference (conv / iconv are Clrfft::transform's own kernels, cl_fft.cpp:267-296).
   cl_mem w, b, data1, data2;
   cl_command_queue commands;
   int fft();
@@ -43,6 +45,10 @@ class Clcfft {
   int transform_device(void *data, long batch, void *stream = 0);
   /** ... from src to dst (the reference's device side is out of place too: data1 -> data2) */
   int transform_device(const void *src, void *dst, long batch, void *stream);
+  /** extension: pin an array the caller keeps for the object's life; transform() calls on arrays inside it then run on that
+      memory directly (no staging copies).  Unpinned by unpin_host() or the destructor; do not free it before. */
+  int pin_host(void *ptr, size_t bytes);
+  int unpin_host(void *ptr);
   /** Get setup error code */
   int get_error() { return cl_err; }
   /** Get compilation log (setup diagnostics here; nothing is JIT-compiled) */
@@ -52,6 +58,8 @@ class Clcfft {
   // not copyable (the reference's implicit copy would double-release its OpenCL handles; here it is ruled out)
   Clcfft(const Clcfft &);
   Clcfft &operator=(const Clcfft &);
+
+  void protected_members();
 
  protected:
   Clcfft(cl_device_id device_id, int size, bool fwd, bool real);

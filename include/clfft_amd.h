@@ -101,6 +101,16 @@ CLFA_API int clfa_cfft_transform(clfa_fft *plan, float *c, long batch);
 /* Clrfft::transform(c, r), cl_fft.cpp:267-296.  forward: r (size floats per
  * batch) -> c (M complex per batch); inverse: c -> r.  c and r may alias. */
 CLFA_API int clfa_rfft_transform(clfa_fft *plan, float *c, float *r, long batch);
+/* Extension to the two host calls above, which replace the reference's blocking clEnqueueWriteBuffer / ReadBuffer around
+ * every transform (cl_fft.cpp:155-158, 275-291): a caller that keeps ONE array for the plan's life (the Csound opcodes keep
+ * one AuxMem buffer per instance, csound/opcode.cpp) pins it once; transform calls on arrays INSIDE a pinned range then run
+ * on that memory directly — the kernels read and write it over PCIe, one pass each way, no staging copy (up to 8 MiB per
+ * call and on the routes that touch source and destination once; otherwise the usual copies, by DMA).  Results are
+ * bit-identical to the unpinned call.  The range stays pinned until unregister or destroy; the caller must not free it
+ * before.  Overlapping a range already pinned, NULL or 0 bytes: CL_INVALID_VALUE; a refusal of the runtime comes back as
+ * its CL-numbered code.  Real plans, out of place: both arrays must be pinned for the direct route. */
+CLFA_API int clfa_fft_host_register(clfa_fft *plan, void *ptr, size_t bytes);
+CLFA_API int clfa_fft_host_unregister(clfa_fft *plan, void *ptr);
 /* device-resident, in place, asynchronous on `stream`: the body of
  * Clcfft::fft() (cl_fft.cpp:138-151) / the kernel part of Clrfft::transform.
  * data: batch * n complex64 (c2c) or batch * size float32 (r2c, packed in place). */
@@ -163,7 +173,10 @@ CLFA_API int clfa_pconv_push_ir_dev(clfa_pconv *pc, const void *ir, long channel
 CLFA_API int clfa_pconv_convolution(clfa_pconv *pc, float *out, const float *in);
 /* Clpconv::convolution(out, in1, in2), cl_conv.cpp:460-548 (time-varying) */
 CLFA_API int clfa_pconv_convolution_tv(clfa_pconv *pc, float *out, const float *in1, const float *in2);
-/* device-resident variants; in2 may be NULL (static IR) */
+/* device-resident variants; in2 may be NULL (static IR).  `out` must not overlap an input, not even partly, on the one-launch
+ * routes (clfa_pconv_kernel_name() = k_pconv_fused or k_pconv_coop: partitions up to 4096 samples), where workgroups of
+ * other channels may still be reading: CL_INVALID_VALUE.  The launch chain of larger partitions reads every input before it
+ * writes `out`; in place is accepted there. */
 CLFA_API int clfa_pconv_process_dev(clfa_pconv *pc, void *out, const void *in1, const void *in2, void *stream);
 CLFA_API size_t clfa_pconv_state_bytes(const clfa_pconv *pc);
 /* which launch structure a block of this object takes (diagnostics and tests): "k_pconv_fused" (one launch, one

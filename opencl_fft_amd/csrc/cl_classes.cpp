@@ -11,19 +11,20 @@ const char *cl_error_string(int err) { return clfa_error_string(err); }   // cl_
 Clcfft::Clcfft(cl_device_id device_id, int size, bool fwd)
     : N(size), forward(fwd), plan(NULL), cl_err(0), w(NULL), b(NULL), data1(NULL), data2(NULL), commands(NULL) {
   cl_err = clfa_cfft_create(&plan, clfa_device_ordinal(device_id), size, fwd ? 1 : 0);
-  if (!cl_err && size <= 65536 && !(size & (size - 1))) {   // the reference's range: its protected members exist
-    clfa_fft_device_buffers(plan, &data1, &data2, &commands);
-    clfa_fft_device_tables(plan, &w, &b);
-  }
+  if (!cl_err && size <= 65536 && !(size & (size - 1))) protected_members();   // the reference's range
+}
+// the reference's protected members (cl_fft.h:31-44), for subclasses; a failure here is a setup error like any other
+// (cl_fft.cpp:79-84: the reference's clCreateBuffer calls feed the same cl_err)
+void Clcfft::protected_members() {
+  cl_err = clfa_fft_device_buffers(plan, &data1, &data2, &commands);
+  if (!cl_err) cl_err = clfa_fft_device_tables(plan, &w, &b);
+  if (cl_err) w = b = data1 = data2 = NULL;
 }
 // Clrfft constructs its base with size/2 (cl_fft.cpp:210): the member N is M = size/2
 Clcfft::Clcfft(cl_device_id device_id, int size, bool fwd, bool)
     : N(size / 2), forward(fwd), plan(NULL), cl_err(0), w(NULL), b(NULL), data1(NULL), data2(NULL), commands(NULL) {
   cl_err = clfa_rfft_create(&plan, clfa_device_ordinal(device_id), size, fwd ? 1 : 0);
-  if (!cl_err && size <= 131072 && !(size & (size - 1))) {
-    clfa_fft_device_buffers(plan, &data1, &data2, &commands);
-    clfa_fft_device_tables(plan, &w, &b);
-  }
+  if (!cl_err && size <= 131072 && !(size & (size - 1))) protected_members();
 }
 int Clcfft::fft() { return clfa_fft_run_buffers(plan); }                   // cl_fft.cpp:138-151
 Clcfft::~Clcfft() { clfa_fft_destroy(plan); }                              // cl_fft.cpp:127-136
@@ -37,6 +38,8 @@ int Clcfft::transform_device(void *data, long batch, void *stream) { return clfa
 int Clcfft::transform_device(const void *src, void *dst, long batch, void *stream) {
   return clfa_fft_exec_dev_oop(plan, src, dst, batch, stream);
 }
+int Clcfft::pin_host(void *ptr, size_t bytes) { return clfa_fft_host_register(plan, ptr, bytes); }
+int Clcfft::unpin_host(void *ptr) { return clfa_fft_host_unregister(plan, ptr); }
 const char *Clcfft::get_log() { return clfa_fft_get_log(plan); }
 
 Clrfft::Clrfft(cl_device_id device_id, int size, bool fwd) : Clcfft(device_id, size, fwd, true) {}   // cl_fft.cpp:208-259

@@ -260,6 +260,13 @@ struct clfa_fft {
   DevBuf half, w2, four, scratch, stage, res16;
   DevBuf own1, own2;     // the reference's protected data1 / data2 (cl_fft.h:35), on request: clfa_fft_device_buffers
   DevBuf own_w, own_b;   // ... and w / b: clfa_fft_device_tables
+  bool own_tables_ready = false;   // both tables allocated AND filled
+  struct Pinned {          // a caller array pinned for the plan's life: clfa_fft_host_register
+    char *h, *d;           // host address, and the same memory as the device sees it
+    size_t bytes;
+  };
+  std::vector<Pinned> pinned;
+  clfa_fft *own_cplx = nullptr;    // Clrfft::fft() = the complex n-point transform alone (cl_fft.cpp:138-151 on N = size / 2): a c2c plan, on demand
   StreamOrder order;
   HostBuf zstage;        // zero-copy staging of small host transforms
   FftTables tabs;
@@ -620,6 +627,9 @@ void clfa_fft_destroy(clfa_fft *p) {
     (void)hipStreamSynchronize(p->stream);
     (void)hipStreamDestroy(p->stream);
   }
+  for (auto &r : p->pinned) (void)hipHostUnregister(r.h);
+  p->pinned.clear();
+  if (p->own_cplx) clfa_fft_destroy(p->own_cplx);
   if (p->blue_f) clfa_fft_destroy(p->blue_f);
   if (p->blue_i) clfa_fft_destroy(p->blue_i);
   p->blue_w.release();
@@ -786,16 +796,22 @@ int clfa_fft_device_tables(clfa_fft *p, void **w, void **b) {
   if (p->blue_m || p->logn < 1 || p->logn > kMaxLog) return CLFA_INVALID_OPERATION;
   ENTER_DEVICE(p->di.device);
   const int n = p->n;
-  if (!p->own_w.p) {
+  if (!p->own_tables_ready) {
     std::vector<cpx> tw;
     fill_twiddle(tw, n, n, 1, p->fwd ? -1.f : 1.f);                 // cl_fft.cpp:86-91
     std::vector<int> br((size_t)n);
     int e = clfa_bitrev_table(n, br.data());                        // cl_fft.cpp:96-101
     if (!e) e = p->own_w.ensure(sizeof(cpx) * (size_t)n);
     if (!e) e = p->own_b.ensure(sizeof(int) * (size_t)n);
-    if (e) return e;
-    HIP_TRY(hipMemcpy(p->own_w.p, tw.data(), sizeof(cpx) * (size_t)n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p->own_b.p, br.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    if (!e) e = map_hip(hipMemcpy(p->own_w.p, tw.data(), sizeof(cpx) * (size_t)n, hipMemcpyHostToDevice));
+    if (!e) e = map_hip(hipMemcpy(p->own_b.p, br.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    if (e) {   // all or nothing: a later call must not hand out a table that was never filled
+      (void)hipGetLastError();
+      p->own_w.release();
+      p->own_b.release();
+      return e;
+    }
+    p->own_tables_ready = true;
   }
   if (w) *w = p->own_w.p;
   if (b) *b = p->own_b.p;
@@ -823,13 +839,27 @@ int clfa_fft_run_buffers(clfa_fft *p) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!p->own1.p || !p->own2.p) return CLFA_INVALID_MEM_OBJECT;
-  return clfa_fft_exec_dev_oop(p, p->own1.p, p->own2.p, 1, p->stream);
+  if (!p->real) return clfa_fft_exec_dev_oop(p, p->own1.p, p->own2.p, 1, p->stream);
+  // a Clrfft's fft() is the complex transform of its N = size / 2 points and nothing else: the reference's conv / iconv
+  // are kernels of their own, enqueued by Clrfft::transform (cl_fft.cpp:267-296), not by fft()
+  if (!p->own_cplx) {
+    const int e = clfa_cfft_create(&p->own_cplx, p->di.device, p->n, p->fwd ? 1 : 0);
+    if (e) {
+      if (p->own_cplx) clfa_fft_destroy(p->own_cplx);
+      p->own_cplx = nullptr;
+      return e;
+    }
+  }
+  return clfa_fft_exec_dev_oop(p->own_cplx, p->own1.p, p->own2.p, 1, p->stream);
 }
 
 // bytes per call up to which the host entry points go zero-copy: the kernels read the input from,
 // and write the result to, mapped pinned host memory (one pass each way), instead of two
 // hipMemcpyAsync calls of 10-15 us each around a kernel of a few microseconds
-constexpr size_t kZeroCopyMax = 256 << 10;
+#ifndef CLFA_ZEROCOPY_MAX_KIB
+#define CLFA_ZEROCOPY_MAX_KIB 256   // (profiles/host_path_r05.txt: above it the two staging memcpys cost more than the DMA copies)
+#endif
+constexpr size_t kZeroCopyMax = (size_t)CLFA_ZEROCOPY_MAX_KIB << 10;
 
 // host staging in chunks of at most ~256 MiB so huge host batches do not need a
 // device buffer of their full size
@@ -840,12 +870,73 @@ static long chunk_batches(size_t bytes_per_batch, long batch) {
   return c < batch ? c : batch;
 }
 
+// ---- caller arrays pinned for the plan's life (extension) ------------------------------------------------------
+// The reference's transform() copies the caller's array to the device and back with two blocking transfers
+// (cl_fft.cpp:155-158).  A caller that keeps ONE array for the object's life — the Csound opcodes do: one AuxMem
+// buffer per instance, csound/opcode.cpp — can pin it once: transform() calls on arrays inside a pinned range then
+// run on that memory directly (the kernels read and write it over PCIe, one pass each way, no staging copy, one
+// synchronisation).  Explicit on purpose: nothing tells the library that an address seen before is still the same
+// allocation, so nothing is pinned behind the caller's back.
+int clfa_fft_host_register(clfa_fft *p, void *ptr, size_t bytes) {
+  if (!p) return CLFA_INVALID_VALUE;
+  if (p->err) return p->err;
+  if (!ptr || !bytes) return CLFA_INVALID_VALUE;
+  for (auto &r : p->pinned)
+    if ((char *)ptr < r.h + r.bytes && r.h < (char *)ptr + bytes) return CLFA_INVALID_VALUE;   // overlaps a pinned range
+  ENTER_DEVICE(p->di.device);
+  void *d = nullptr;
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped);
+  if (e == hipSuccess && (e = hipHostGetDevicePointer(&d, ptr, 0)) != hipSuccess) (void)hipHostUnregister(ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return map_hip(e);
+  }
+  p->pinned.push_back({(char *)ptr, (char *)d, bytes});
+  return CLFA_SUCCESS;
+}
+int clfa_fft_host_unregister(clfa_fft *p, void *ptr) {
+  if (!p) return CLFA_INVALID_VALUE;
+  for (size_t i = 0; i < p->pinned.size(); i++)
+    if (p->pinned[i].h == (char *)ptr) {
+      ENTER_DEVICE(p->di.device);
+      if (p->stream) (void)hipStreamSynchronize(p->stream);
+      (void)hipHostUnregister(ptr);
+      p->pinned.erase(p->pinned.begin() + (long)i);
+      return CLFA_SUCCESS;
+    }
+  return CLFA_INVALID_VALUE;
+}
+// device view of [h, h + bytes) if it lies inside a pinned range, else NULL
+static void *pinned_dev(const clfa_fft *p, const void *h, size_t bytes) {
+  for (auto &r : p->pinned)
+    if ((const char *)h >= r.h && (const char *)h + bytes <= r.h + r.bytes) return r.d + ((const char *)h - r.h);
+  return nullptr;
+}
+// Pinned arrays up to this size run zero-copy when the plan's route touches its source and its destination once each
+// (every route of the reference's range except the launch chains with a pack / unpack pass of their own); beyond it, and
+// on the other routes, they are copied by DMA like pageable arrays, only faster.
+constexpr size_t kPinnedZeroCopyMax = (size_t)8 << 20;
+static bool one_touch_route(const clfa_fft *p, long batch) {
+  if (p->blue_m || p->logn > kMaxLog) return false;
+  if (!p->real) return true;
+  if (p->logn <= kLdsMaxLog) return true;
+  return batch > p->spread_below && (p->rlds15 || p->r2x13 || (p->r16 && batch * 4 > fourstep_grid(p->di)));
+}
+
 int clfa_cfft_transform(clfa_fft *p, float *c, long batch) {
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!c || batch < 0 || p->real) return CLFA_INVALID_VALUE;
   ENTER_DEVICE(p->di.device);
   const size_t per = sizeof(cpx) * (size_t)p->n;
+  if (batch > 0 && per * (size_t)batch <= kPinnedZeroCopyMax && one_touch_route(p, batch)) {
+    if (void *dv = pinned_dev(p, c, per * (size_t)batch)) {   // the caller's own array, pinned: in place over PCIe
+      const int e = clfa_fft_exec_dev(p, dv, batch, p->stream);
+      if (e) return e;
+      HIP_TRY(hipStreamSynchronize(p->stream));
+      return CLFA_SUCCESS;
+    }
+  }
   if (batch > 0 && per * (size_t)batch <= kZeroCopyMax) {
     int e = p->zstage.ensure(per * batch);
     if (e) return e;
@@ -875,6 +966,16 @@ int clfa_rfft_transform(clfa_fft *p, float *c, float *r, long batch) {
   if (!c || !r || batch < 0 || !p->real) return CLFA_INVALID_VALUE;
   ENTER_DEVICE(p->di.device);
   const size_t per = sizeof(cpx) * (size_t)p->n;  // size floats == M complex
+  if (batch > 0 && per * (size_t)batch <= kPinnedZeroCopyMax && one_touch_route(p, batch)) {
+    void *src = p->fwd ? (void *)r : (void *)c, *dst = p->fwd ? (void *)c : (void *)r;
+    void *ds = pinned_dev(p, src, per * (size_t)batch), *dd = src == dst ? ds : pinned_dev(p, dst, per * (size_t)batch);
+    if (ds && dd) {   // both of the caller's arrays pinned (or one, in place)
+      const int e = clfa_fft_exec_dev_oop(p, ds, dd, batch, p->stream);
+      if (e) return e;
+      HIP_TRY(hipStreamSynchronize(p->stream));
+      return CLFA_SUCCESS;
+    }
+  }
   if (batch > 0 && per * (size_t)batch <= kZeroCopyMax) {
     int e = p->zstage.ensure(per * batch);
     if (e) return e;
@@ -1074,9 +1175,11 @@ int clfa_pconv_process_dev(clfa_pconv *p, void *out, const void *in1, const void
   if (!p) return CLFA_INVALID_VALUE;
   if (p->err) return p->err;
   if (!out || !in1) return CLFA_INVALID_VALUE;
-  {
-    // the kernels read the inputs of ALL channels while workgroups of other channels may already write their output
-    // (the buffers are __restrict__): any overlap of out with an input — not only equal pointers — is refused
+  if (p->fused || p->coop.logs >= 0) {
+    // the one-launch routes read the inputs of ALL channels while workgroups of other channels may already write their
+    // output (the buffers are __restrict__): any overlap of out with an input — not only equal pointers — is refused.
+    // (The launch chain below has read every input when its forward launch ends, before the inverse launch writes `out`:
+    // in place is fine there, as it was for the reference's host arrays.)
     const size_t blk = sizeof(float) * (size_t)p->pts * (size_t)p->g.channels;
     if (ranges_overlap(out, in1, blk) || (in2 && ranges_overlap(out, in2, blk))) return CLFA_INVALID_VALUE;
   }

@@ -594,6 +594,16 @@ __device__ __forceinline__ void handover_acquire(int acquire) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 }
+// The arriving lane's add carries the C++ model's release as well (CLFA_HANDOVER_RELEASE): the hand-written form above
+// orders the slice stores in hardware, but nothing in it tells hipcc that they must stay above the add — with the
+// release a future compiler cannot sink a slice store below the counter.  On gfx950 it costs a buffer_wbl2 sc1 and a wait
+// in ONE lane after the barrier (profiles/handover_release_r05.txt).
+#ifndef CLFA_HANDOVER_RELEASE
+#define CLFA_HANDOVER_RELEASE 1
+#endif
+__device__ __forceinline__ unsigned handover_arrive(unsigned *counter) {
+  return __hip_atomic_fetch_add(counter, 1u, CLFA_HANDOVER_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void st_agent(cpx *p, cpx v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
@@ -839,7 +849,7 @@ __global__ __launch_bounds__(LdsGeom<LOGB>::WG) void k_pconv_coop(const float *_
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(counters + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = handover_arrive(counters + ch);
     s_last = old == (unsigned)(S * sparts - 1);
     if (s_last) {
       __hip_atomic_store(counters + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch
@@ -1149,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_dconv_block(float *__restrict__ out, co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(counters + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = handover_arrive(counters + y);
     s_last = old == (unsigned)(G - 1);
     if (s_last) {
       __hip_atomic_store(counters + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next block's launch

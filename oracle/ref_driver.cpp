@@ -140,13 +140,60 @@ static void run_g11(cl_device_id dev) {
   run_dconv("g11_tvdconv_i256_v32", 256, 32, 30, true);
 }
 
+// PCI bus number of an OpenCL device (AMD's cl_amd_device_attribute_query: CL_DEVICE_TOPOLOGY_AMD), -1 if unknown
+static int pci_bus_of(cl_device_id d) {
+  struct {
+    cl_uint type;
+    cl_char unused[17];
+    cl_char bus, device, function;
+  } topo;
+  memset(&topo, 0, sizeof(topo));
+  if (clGetDeviceInfo(d, 0x4037 /* CL_DEVICE_TOPOLOGY_AMD */, sizeof(topo), &topo, NULL) != CL_SUCCESS || topo.type != 1) return -1;
+  return (int)(unsigned char)topo.bus;
+}
+
+// ---- timing of the reference's own calls (bench.py / tools/rt_sweep.py run these live; nothing is written) ----------
+// Clrfft::transform(c, r), forward / inverse alternating (cl_fft.cpp:267-296): "<us per call> <G real samples/s> <calls>"
+static int time_rfft(cl_device_id dev, int size, const char *name) {
+  cl_fft::Clrfft f(dev, size, true), g(dev, size, false);
+  if (f.get_error() != CL_SUCCESS || g.get_error() != CL_SUCCESS) return 4;
+  std::vector<float> r(size);
+  std::vector<cf> c(size / 2);
+  Lcg l(12345);
+  for (auto &v : r) v = l.sym();
+  for (int k = 0; k < 4; k++) (k & 1) ? g.transform(c.data(), r.data()) : f.transform(c.data(), r.data());
+  const int reps = 200;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < reps; k++) (k & 1) ? g.transform(c.data(), r.data()) : f.transform(c.data(), r.data());
+  auto t1 = std::chrono::steady_clock::now();
+  const double us = std::chrono::duration<double, std::micro>(t1 - t0).count() / reps;
+  printf("%.3f %.6f %d %s\n", us, size / us * 1e-3, reps, name);
+  return 0;
+}
+// Clpconv::convolution per block, one instance (cl_conv.cpp:393-458 static / 460-548 time-varying): microseconds per block
+static double time_pconv_block(cl_device_id dev, int pts, int cvs, bool tv, int blocks) {
+  cl_conv::Clpconv c(dev, cvs, pts);
+  if (c.get_cl_err() != CL_SUCCESS) return -1.0;
+  Lcg l(7);
+  std::vector<float> ir((size_t)(cvs / pts) * pts), a(pts), b(pts), out(pts);
+  const float g = 1.0f / std::sqrt((float)cvs);
+  for (auto &v : ir) v = l.half() * g;
+  for (auto &v : a) v = l.sym();
+  for (auto &v : b) v = l.half() * g;
+  if (!tv && c.push_ir(ir.data()) != CL_SUCCESS) return -1.0;
+  for (int k = 0; k < 3; k++) tv ? c.convolution(out.data(), a.data(), b.data()) : c.convolution(out.data(), a.data());
+  auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < blocks; k++) tv ? c.convolution(out.data(), a.data(), b.data()) : c.convolution(out.data(), a.data());
+  auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::micro>(t1 - t0).count() / blocks;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: ref_driver <outdir> [device-index] [g11 | time]\n");
+    fprintf(stderr, "usage: ref_driver <outdir> [device-index | pci:<bus>] [g11 | time | time-rfft <size> | time-pconv <pts> <cvs> <blocks> [tv] | rt-sweep <blocks>]\n");
     return 2;
   }
   g_dir = argv[1];
-  int devidx = argc > 2 ? atoi(argv[2]) : 0;
   cl_device_id ids[32];
   cl_uint num = 0;
   int err = clGetDeviceIDs(NULL, CL_DEVICE_TYPE_ALL, 32, ids, &num);
@@ -154,10 +201,56 @@ int main(int argc, char **argv) {
     fprintf(stderr, "no OpenCL device: %s\n", cl_fft::cl_error_string(err));
     return 3;
   }
-  char name[128] = {0};
+  // the device: an index into clGetDeviceIDs' list (as the reference's callers pick it), or pci:<bus> — the OpenCL device on
+  // that PCI bus, which is how bench.py names the GPU its own rank runs on (OpenCL's enumeration need not follow HIP's)
+  int devidx = 0;
+  if (argc > 2 && !strncmp(argv[2], "pci:", 4)) {
+    const int want = (int)strtol(argv[2] + 4, NULL, 16);
+    devidx = -1;
+    for (cl_uint i = 0; i < num; i++)
+      if (pci_bus_of(ids[i]) == want) devidx = (int)i;
+    if (devidx < 0) {
+      fprintf(stderr, "no OpenCL device on PCI bus %02x\n", want);
+      return 3;
+    }
+  } else if (argc > 2) {
+    devidx = atoi(argv[2]);
+  }
+  if (devidx < 0 || devidx >= (int)num) {
+    fprintf(stderr, "device index %d out of range (%u devices)\n", devidx, num);
+    return 3;
+  }
+  char name[160] = {0};
   clGetDeviceInfo(ids[devidx], CL_DEVICE_NAME, 128, name, NULL);
+  {
+    const int bus = pci_bus_of(ids[devidx]);
+    if (bus >= 0) snprintf(name + strlen(name), sizeof(name) - strlen(name), " [pci bus %02x]", bus);
+  }
   fprintf(stderr, "ref_driver: %u device(s), using %d: %s\n", num, devidx, name);
   cl_device_id dev = ids[devidx];
+
+  if (argc > 3 && !strcmp(argv[3], "time-rfft")) return time_rfft(dev, argc > 4 ? atoi(argv[4]) : 16384, name);
+  if (argc > 6 && !strcmp(argv[3], "time-pconv")) {
+    // "<us per block> <G samples/s of one instance> <blocks> <device>"
+    const int pts = atoi(argv[4]), cvs = atoi(argv[5]), blocks = atoi(argv[6]);
+    const double us = time_pconv_block(dev, pts, cvs, argc > 7 && !strcmp(argv[7], "tv"), blocks);
+    if (us < 0) return 4;
+    printf("%.3f %.6f %d %s\n", us, pts / us * 1e-3, blocks, name);
+    return 0;
+  }
+  if (argc > 3 && !strcmp(argv[3], "rt-sweep")) {
+    // the grid of the reference's own benchmark (csound/tests.py:10-36: cltvconv, partition M = 2^{9,11,13,15} x filter
+    // length L = 2^16..2^22): one line per cell, "<M> <log2 L> <us per block>", time-varying convolution, one instance
+    const int blocks = argc > 4 ? atoi(argv[4]) : 50;
+    printf("# %s\n", name);
+    for (int m : {9, 11, 13, 15})
+      for (int l = 16; l <= 22; l++) {
+        const double us = time_pconv_block(dev, 1 << m, 1 << l, true, blocks);
+        printf("%d %d %.3f\n", 1 << m, l, us);
+        fflush(stdout);
+      }
+    return 0;
+  }
 
   if (argc > 3 && !strcmp(argv[3], "time")) {
     // only the timing of the reference's own path (bench.py runs this live where an OpenCL device exists): one line on stdout,

@@ -37,6 +37,24 @@ struct PeekCfft : cl_fft::Clcfft {
   bool is_forward() const { return forward; }
 };
 
+// ... and a subclass of Clrfft: there the inherited N is size / 2 and fft() is the complex N-point transform of
+// data1 -> data2 ALONE (cl_fft.cpp:210, 138-151); the pack / unpack kernels belong to Clrfft::transform (cl_fft.cpp:267-296)
+struct PeekRfft : cl_fft::Clrfft {
+  PeekRfft(cl_device_id d, int size, bool fwd) : Clrfft(d, size, fwd) {}
+  int complex_points() const { return N; }
+  int own_fft(cf *c) {
+    clEnqueueWriteBuffer(commands, data1, CL_TRUE, 0, sizeof(cl_float2) * N, c, 0, NULL, NULL);
+    int err = fft();
+    clEnqueueReadBuffer(commands, data2, CL_TRUE, 0, sizeof(cl_float2) * N, c, 0, NULL, NULL);
+    return err;
+  }
+  std::vector<cf> twiddle() {
+    std::vector<cf> t(N);
+    clEnqueueReadBuffer(commands, w, CL_TRUE, 0, sizeof(cl_float2) * N, t.data(), 0, NULL, NULL);
+    return t;
+  }
+};
+
 int main() {
   cl_device_id ids[32];
   cl_uint num = 0;
@@ -78,6 +96,31 @@ int main() {
         bad += g.size() != 2048 || !golden::parity(reinterpret_cast<float *>(y.data()), g.data(), 2048, 1e-6, "subclass fft() vs reference");
       }
     }
+  }
+  // Clrfft(2048): N = 1024 and fft() must be the reference's 1024-point complex transform (G3), packed nothing
+  for (int fwd = 1; fwd >= 0; fwd--) {
+    PeekRfft p(ids[0], 2048, fwd != 0);
+    if (p.get_error() != 0 || p.complex_points() != 1024) return 1;
+    const std::vector<cf> tw = p.twiddle();   // the base class's table on N = 1024 points (cl_fft.cpp:86-91)
+    for (int i = 0; i < 1024; i++) {
+      const float re = (float)cos(i * 2 * cl_fft::PI / 1024), im = (fwd ? -1.f : 1.f) * (float)sin(i * 2 * cl_fft::PI / 1024);
+      if (tw[i].real() != re || tw[i].imag() != im) bad++;
+    }
+    golden::Lcg r(12345);
+    std::vector<cf> x(1024);
+    for (auto &c : x) {
+      float re = r.sym();
+      float im = r.sym();
+      c = cf(re, im);
+    }
+    if (p.own_fft(x.data()) != 0) return 1;
+    const std::vector<float> g = golden::load_f32(fwd ? "g3_cfft1024_fwd" : "g3_cfft1024_inv");
+    bad += g.size() != 2048 || !golden::parity(reinterpret_cast<float *>(x.data()), g.data(), 2048, 1e-6, "Clrfft subclass fft() vs reference cfft");
+    // the object still transforms real data afterwards (the sub-plan shares nothing with the packed real plan)
+    std::vector<float> re(2048);
+    for (auto &v : re) v = r.sym();
+    std::vector<cf> spec(1024);
+    if (fwd && p.transform(spec.data(), re.data()) != 0) return 1;
   }
   std::cout << (bad ? "FAIL" : "OK") << std::endl;
   return bad ? 1 : 0;

@@ -61,6 +61,37 @@ def test_pconv_ring_indices_bit_exact():
         assert (q.wp, q.wp2) == (oq.wp, oq.wp2)
 
 
+def test_pconv_device_overlap_contract():
+    """clfa_pconv_process_dev: `out` overlapping an input is refused on the one-launch routes (other channels' workgroups may
+    still be reading); the launch chain of partitions above 4096 samples has read every input before it writes and runs in
+    place, block for block what the oracle gives (the reference's own calls are on host arrays, cl_conv.cpp:393-458)"""
+    import torch
+    for pts, nparts in ((1024, 3), (256, 2)):
+        p = fa.Clpconv(0, pts * nparts, pts)
+        assert p.kernel_name() in ("k_pconv_fused", "k_pconv_coop")
+        buf = torch.zeros(2 * pts, device="cuda")
+        assert p.process_device(buf[:pts], buf[:pts]) == -30
+        assert p.process_device(buf[pts // 2:pts // 2 + pts], buf[:pts]) == -30
+        assert p.process_device(buf[pts:], buf[:pts], buf[1:pts + 1]) == -30
+        assert (p.wp, p.wp2) == (0, nparts - 1)            # a refused call moves no ring index
+        assert p.process_device(buf[pts:], buf[:pts]) == 0
+    pts, nparts, blocks = 8192, 2, 4
+    s = util.lcg_half(99, pts * nparts + pts * blocks)
+    ir, x = s[:pts * nparts], s[pts * nparts:]
+    p, o = fa.Clpconv(0, pts * nparts, pts), oracle.Pconv(pts * nparts, pts)
+    assert p.kernel_name() not in ("k_pconv_fused", "k_pconv_coop")
+    assert p.push_ir(ir) == 0
+    o.push_ir(ir)
+    d = torch.from_numpy(x.copy()).cuda()
+    for b in range(blocks):
+        blk = d[b * pts:(b + 1) * pts]
+        assert p.process_device(blk, blk) == 0             # in place
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    for b in range(blocks):
+        assert_parity(got[b * pts:(b + 1) * pts], o.convolution(x[b * pts:(b + 1) * pts]), tol=CTOL, what="in-place block %d" % b)
+
+
 @pytest.mark.parametrize("pts,nparts,channels,blocks", [(2, 1, 3, 4), (16, 5, 7, 12), (256, 3, 5, 8), (1024, 6, 3, 9),
                                                         (4096, 2, 2, 5), (8192, 2, 1, 4), (16384, 2, 2, 4),
                                                         (32768, 3, 1, 5)])

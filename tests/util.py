@@ -80,3 +80,66 @@ def assert_parity(y, ref, tol=TOL, what=""):
     l2, mx = rel_err(y, ref)
     assert l2 <= tol and mx <= tol, "%s: relL2=%.3g max/max=%.3g (tol %.1g)" % (what, l2, mx, tol)
     return l2, mx
+
+
+# ---- float64 evaluations of the reference's convolution formulas (tests/test_gpu_conv_accuracy.py) ------------------
+def _block_spectra64(x, pts):
+    """rfft of every pts-sample block zero-padded to 2 pts (float64): the spectra the reference's forward chain produces
+    (cl_conv.cpp:399-419), up to its packing of bins 0 and pts"""
+    blocks = x.size // pts
+    z = np.zeros((blocks, 2 * pts), np.float64)
+    z[:, :pts] = np.asarray(x, np.float64).reshape(blocks, pts)
+    return np.fft.rfft(z, axis=1)
+
+
+def _olap64(Y, pts):
+    """c2r + inverse transform + overlap-add (cl_conv_kernels.h:87-100, 120-124) of block spectra Y; the packed bin 0 of the
+    reference carries HALF the DC / Nyquist values on both operands of the product, one of which its inverse map undoes:
+    bins 0 and pts of every product have gain 1/2"""
+    Y = Y.copy()
+    Y[:, 0] *= 0.5
+    Y[:, pts] *= 0.5
+    y = np.fft.irfft(Y, n=2 * pts, axis=1)
+    out = y[:, :pts].copy()
+    out[1:] += y[:-1, pts:]
+    return out.reshape(-1)
+
+
+def pconv_f64(ir, x, pts):
+    """Clpconv::push_ir + convolution(out, in) (cl_conv.cpp:353-458) in float64: block t = sum over partitions p of
+    X[t - p] H[p], overlap-added"""
+    X, H = _block_spectra64(x, pts), _block_spectra64(ir[:(ir.size // pts) * pts], pts)
+    Y = np.zeros_like(X)
+    for p in range(H.shape[0]):
+        Y[p:] += X[:X.shape[0] - p] * H[p] if p else X * H[0]
+    return _olap64(Y, pts)
+
+
+def pconv_tv_f64(x1, x2, pts, nparts):
+    """Clpconv::convolution(out, in1, in2) (cl_conv.cpp:460-548) in float64: block T = sum over a < nparts of
+    X1[T - a] X2[t'(a)], t'(a) = the most recent block index <= T congruent to a mod nparts — the second input's block t
+    overwrites "partition t mod nparts" """
+    X1, X2 = _block_spectra64(x1, pts), _block_spectra64(x2, pts)
+    Y = np.zeros_like(X1)
+    for T in range(X1.shape[0]):
+        for a in range(min(nparts, T + 1)):
+            tp = T - ((T - a) % nparts)
+            if tp >= 0:
+                Y[T] += X1[T - a] * X2[tp]
+    return _olap64(Y, pts)
+
+
+def dconv_last_block(ir, x, vsize, b, pick):
+    """Cldconv::convolution (cl_dconv.cpp:32-43, 109-132), outputs `pick` of block b (the delay line full): out[i] =
+    sum_k ir[k] x[i - 1 - k].  Returns (float64 value, float32 products added one by one in the kernel's tap order h =
+    irsize - 1 - k ascending — the oracle's arithmetic, oracle/clfft_oracle.c orc_dconv_convolution)"""
+    irsize = ir.size
+    rev = np.ascontiguousarray(ir[::-1])
+    truth, seq = np.empty(len(pick), np.float64), np.empty(len(pick), np.float32)
+    for j, n in enumerate(pick):
+        i0 = b * vsize - irsize + int(n)
+        assert i0 >= 0
+        seg = x[i0:i0 + irsize]
+        truth[j] = np.dot(seg.astype(np.float64), rev.astype(np.float64))
+        seq[j] = np.cumsum(seg * rev, dtype=np.float32)[-1]
+    return truth, seq

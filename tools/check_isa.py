@@ -128,7 +128,8 @@ def check(path):
 def check_handover(path):
     """conv_kernels.hip: the inter-workgroup hand-overs of k_pconv_coop / k_dconv_block read the handed-over bytes with
     agent-scope loads that must compile to global_ / buffer_ loads with sc1 (never flat_: MI355X_MICROARCH.md, 'Valid
-    forms', Consumer bullet), store them with sc1 stores, drain with s_waitcnt vmcnt(0) in front of the arrival add, and —
+    forms', Consumer bullet), store them with sc1 stores, drain with s_waitcnt vmcnt(0) in front of the arrival add (which
+    is an agent-scope RELEASE in the C++ model as well), and —
     for launches with more workgroups than CUs — carry an agent-scope acquire (buffer_inv sc1) for the last workgroup."""
     s = open(path).read()
     problems = []
@@ -152,6 +153,13 @@ def check_handover(path):
                 problems.append("%s: no sc1 (write-through) store of the handed-over bytes" % name)
             if not any(re.match(r"(global|buffer)_atomic_add\S*\s.*\bsc0\b", c) or re.match(r"(global|buffer)_atomic_add", c) for c in code):
                 problems.append("%s: no arrival counter add" % name)
+            # the arrival add carries an agent-scope release (conv_kernels.hip, handover_arrive): a write-back and its wait
+            # directly in front of every counter add
+            adds = [i for i, c in enumerate(code) if re.match(r"(global|buffer)_atomic_add", c)]
+            for i in adds:
+                before = [c for c in code[max(0, i - 6):i] if c]
+                if not any(c.startswith("buffer_wbl2") and "sc1" in c for c in before) or not any(c.startswith("s_waitcnt") and "vmcnt(0)" in c for c in before):
+                    problems.append("%s: counter add without an agent-scope release (buffer_wbl2 sc1 + s_waitcnt vmcnt(0)) in front of it" % name)
             if not any(c.startswith("buffer_inv") and "sc1" in c for c in code):
                 problems.append("%s: no agent-scope acquire (buffer_inv sc1) for launches beyond one workgroup per CU" % name)
     return problems
