@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2c", choices=["c2c", "rfft", "pconv"])
+    ap.add_argument("--workload", default="c2c", choices=["c2c", "rfft", "pconv", "rfft131072"])
     ap.add_argument("--batch", type=int, default=0, help="override batches / channels per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bandwidth", action="store_true", help="skip the device copy/read/write yardsticks")
@@ -217,7 +217,7 @@ class Workload:
         elif name == "rfft131072":
             # not a BASELINE config: the largest packed real size of the reference's range (cl_fft.cpp:32), in ONE HBM pass
             # since round 4 (the resident kernel with the reference's pair maps inside)
-            size, batch = 131072, batch_override or 2048
+            size, batch = 131072, batch_override or 4096   # 2 GiB in place, the headline's footprint (profiles/r05_rfft131072/ is taken at this batch)
             self.batch, self.n = batch, size
             self.data = torch.rand((batch, size), generator=g, device=dev, dtype=torch.float32) * 2 - 1
             self.plans = [fa.Clrfft(local, size, True), fa.Clrfft(local, size, False)]
@@ -552,7 +552,7 @@ def main():
             pci_bus = int(torch.cuda.get_device_properties(local).pci_bus_id)
         except (AttributeError, TypeError, ValueError):
             pci_bus = None
-        rec["reference_opencl_same_gpu"] = reference_timing({"c2c": "cfft", "rfft": "rfft", "pconv": "pconv"}[a.workload], pci_bus)
+        rec["reference_opencl_same_gpu"] = reference_timing({"c2c": "cfft", "rfft": "rfft", "pconv": "pconv", "rfft131072": "rfft"}[a.workload], pci_bus) if a.workload != "rfft131072" else None
         if others is not None:
             for leg in ("rfft", "pconv"):
                 if leg in others:

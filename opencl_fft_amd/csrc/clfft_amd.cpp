@@ -857,9 +857,10 @@ int clfa_fft_run_buffers(clfa_fft *p) {
 // and write the result to, mapped pinned host memory (one pass each way), instead of two
 // hipMemcpyAsync calls of 10-15 us each around a kernel of a few microseconds
 #ifndef CLFA_ZEROCOPY_MAX_KIB
-#define CLFA_ZEROCOPY_MAX_KIB 256   // (profiles/host_path_r05.txt: above it the two staging memcpys cost more than the DMA copies)
+#define CLFA_ZEROCOPY_MAX_KIB 512   // (profiles/host_path_r05.txt: one N = 65536 transform, 512 KiB: 59.5 us this way, 73.5 by copies)
 #endif
 constexpr size_t kZeroCopyMax = (size_t)CLFA_ZEROCOPY_MAX_KIB << 10;
+constexpr size_t kZeroCopyMaxConv = (size_t)256 << 10;   // the convolutions' blocks (measured at this size only)
 
 // host staging in chunks of at most ~256 MiB so huge host batches do not need a
 // device buffer of their full size
@@ -931,7 +932,18 @@ int clfa_cfft_transform(clfa_fft *p, float *c, long batch) {
   const size_t per = sizeof(cpx) * (size_t)p->n;
   if (batch > 0 && per * (size_t)batch <= kPinnedZeroCopyMax && one_touch_route(p, batch)) {
     if (void *dv = pinned_dev(p, c, per * (size_t)batch)) {   // the caller's own array, pinned: in place over PCIe
-      const int e = clfa_fft_exec_dev(p, dv, batch, p->stream);
+      // measured per call (profiles/host_path_r05.txt): up to 256 KiB the kernels read AND write the caller's memory
+      // (N = 32768: 32.1 us; the copy engine in front costs 5, on both sides 11 more); above it the copy engine brings the
+      // array in and the kernels write the caller's memory (N = 65536: 48.9 us against 52.7 both ways by the kernels, 52.6
+      // both ways by the copy engine, 73.5 for a pageable array through the runtime's own staging)
+      int e;
+      if (per * (size_t)batch <= ((size_t)256 << 10)) {
+        e = clfa_fft_exec_dev(p, dv, batch, p->stream);
+      } else {
+        if ((e = p->stage.ensure(per * batch))) return e;
+        HIP_TRY(hipMemcpyAsync(p->stage.p, c, per * batch, hipMemcpyHostToDevice, p->stream));
+        e = clfa_fft_exec_dev_oop(p, p->stage.p, dv, batch, p->stream);
+      }
       if (e) return e;
       HIP_TRY(hipStreamSynchronize(p->stream));
       return CLFA_SUCCESS;
@@ -1232,7 +1244,7 @@ static int pconv_host(clfa_pconv *p, float *out, const float *in1, const float *
   ENTER_DEVICE(p->di.device);
   const size_t blk = sizeof(float) * (size_t)p->g.channels * p->pts;
   int e;
-  if (blk <= kZeroCopyMax) {
+  if (blk <= kZeroCopyMaxConv) {
     // one audio block of a few channels: the kernels read the input from, and write the output to,
     // mapped pinned host memory — no copy calls, one synchronisation (cl_conv.cpp:399, 455)
     if ((e = p->zin1.ensure(blk)) || (e = p->zout.ensure(blk)) || (in2 && (e = p->zin2.ensure(blk)))) return e;

@@ -416,6 +416,37 @@ struct LaneTab14 {
   const cpx *s256;    // LDS: [256 k] = W_4096^(2^k (tid & 255)), k = 0..3
   cpx w1, w2, w3;     // W_16384^(tid), ^(2 tid), ^(3 tid) (forward sign)
 };
+#ifndef CLFA_ROW16_STRIDE
+#define CLFA_ROW16_STRIDE 18
+#endif
+constexpr int kRow16StrideDev = CLFA_ROW16_STRIDE;
+// The eight-points-per-lane chains (packed real size 8192: two 2048-point runs, passes 8 x 8 x 8 x 4) take the
+// twiddles of the passes that start at 8 and at 64 points from tables of their own in [t][j] order — entry (t, j) =
+// W_(NS R)^(j t) at (t - 1) NS + j, j = tid & (NS - 1) — so that neighbouring lanes read neighbouring entries; in the half
+// table they are 64 t (NS = 8) and 8 t (NS = 64) dwords apart: 8- and 4..16-way conflicts on every read.
+template <int NP> struct PassTabs {
+  const cpx *half;     // LDS: W_n^k, k < n / 2 (the remainder pass and the pair maps)
+  const cpx *p[NP];    // LDS: table of the pass that starts at 2^((k + 1) LOGE) points, at the lane's j
+};
+template <class Tab> struct pass_tabs_count : std::integral_constant<int, 0> {};
+template <int NP> struct pass_tabs_count<PassTabs<NP>> : std::integral_constant<int, NP> {};
+template <int LOGN, bool FWD, int NP> CLFA_HD cpx cmul_tw(cpx v, const PassTabs<NP> &tab, int k) { return cmul_tw<LOGN, FWD>(v, tab.half, k); }
+constexpr int pass_tab_size(int logns, int logr) { return ((1 << logr) - 1) << logns; }
+template <int LOGN, int LOGNS, int LOGR> CLFA_HD void lds_fill_pass_tab(cpx *dst, const cpx *half_g, int tid, int nthreads) {
+  constexpr int N = 1 << LOGN, NS = 1 << LOGNS;
+  for (int i = tid; i < pass_tab_size(LOGNS, LOGR); i += nthreads) {
+    const int t = (i >> LOGNS) + 1, j = i & (NS - 1);
+    const int e = ((j * t) << (LOGN - LOGNS - LOGR)) & (N - 1);
+    const cpx w = half_g[e & (N / 2 - 1)];
+    dst[i] = e & (N / 2) ? mk(-w.x, -w.y) : w;
+  }
+}
+// v[t] times the pass table's entry t (radix = points per lane: one butterfly per lane)
+template <int LOGNS, int R, bool FWD> CLFA_HD void pass_tab_tw(cpx (&v)[R], const cpx *pt) {
+  v[1] = cmulc<!FWD>(v[1], pt[0]);
+#pragma unroll
+  for (int t = 2; t < R; t += 2) cmulc2<!FWD>(v[t], v[t + 1], v[t], pt[(t - 1) << LOGNS], v[t + 1], pt[t << LOGNS]);
+}
 template <class Tab> struct is_lane_tab : std::false_type {};
 template <> struct is_lane_tab<LaneTab13> : std::true_type {};
 template <> struct is_lane_tab<LaneTab14> : std::true_type {};
@@ -472,6 +503,9 @@ template <int LOGNS, bool FWD> CLFA_HD void lane_tw(cpx (&v)[16], const LaneTab1
 template <bool FWD> CLFA_HD void lane_tw_paired(cpx (&v)[16], int tid, const LaneTab13 &tab) { lane_tw13_paired<FWD>(v, tid, tab); }
 template <bool FWD> CLFA_HD void lane_tw_paired(cpx (&v)[16], int tid, const LaneTab14 &tab) { lane_tw14_paired<FWD>(v, tid, tab); }
 
+// lane permutation of the middle passes of the 512- / 1024-lane chains (fft_wg.hpp, wg_passes_sigma): bits 4 and 8 swapped
+CLFA_HD int lane_sigma(int t) { return (t & ~0x110) | ((t & 0x10) << 4) | ((t & 0x100) >> 4); }
+
 // One pass on the registers of lane `tid`: input twiddles then U butterflies.
 template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
 CLFA_HD void pass_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
@@ -480,6 +514,8 @@ CLFA_HD void pass_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
   if constexpr (LOGNS > 0 && is_lane_tab<Tab>::value) {
     static_assert((LOGN == 13 || LOGN == 14) && LOGE == 4, "lane tables exist for 8192 and 16384 points");
     lane_tw<LOGNS, FWD>(v, tab);
+  } else if constexpr (LOGNS > 0 && LOGR == LOGE && LOGNS % LOGE == 0 && LOGNS / LOGE <= pass_tabs_count<Tab>::value) {
+    pass_tab_tw<LOGNS, E, FWD>(v, tab.p[LOGNS / LOGE - 1]);
   } else if constexpr (LOGNS > 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -580,6 +616,8 @@ CLFA_HD void dif_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
   if constexpr (LOGNS > 0 && is_lane_tab<Tab>::value) {
     lane_tw<LOGNS, FWD>(v, tab);
+  } else if constexpr (LOGNS > 0 && LOGR == LOGE && LOGNS % LOGE == 0 && LOGNS / LOGE <= pass_tabs_count<Tab>::value) {
+    pass_tab_tw<LOGNS, E, FWD>(v, tab.p[LOGNS / LOGE - 1]);
   } else if constexpr (LOGNS > 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {

@@ -179,6 +179,9 @@ __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const c
   }
 }
 
+#ifndef CLFA_LANE_SIGMA
+#define CLFA_LANE_SIGMA 1   // n = 8192: the middle passes on permuted lanes (fft_wg.hpp, wg_passes_sigma): conflict-free gathers
+#endif
 template <int LOGN, bool FWD, int MODE, bool SCALE>
 __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k_fft_lds(cpx *__restrict__ data,
                                                               const cpx *__restrict__ tab_g,
@@ -232,7 +235,6 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
 #pragma unroll
     for (int k = 0; k < (LOGN == 14 ? 3 : 1); k++) wl[k] = tab_g[kLane13Lds + k * T + t];
   }
-  const cpx *tab1 = s_tab;
 
   // pack / unpack twiddles of this lane's pairs are the same for every transform
   constexpr int NP = (MODE == MODE_C2C) ? 1 : (E / 2 > 0 ? E / 2 : 1);
@@ -302,6 +304,9 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       if constexpr (LOGN == 14) return LaneTab14{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl[0], wl[1], wl[2]};
       else return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl[0]};
     }();
+    // (n = 256 .. 4096 with a 16 x 16 table for the pass that starts at 16 points — the lane tables' first part — was
+    // measured: -0.2 .. -1.3 % at n <= 2048, +2.2 % at n = 4096, profiles/ab_small_twiddle_tables_r05.txt: not kept)
+    const cpx *tab1 = s_tab;
     const long b = g * FPW + f;
     const bool active = b < batch;
     cpx *x = data + (active ? b : batch - 1) * (long)N;
@@ -360,7 +365,14 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
         pass_gather_padded<LOGN, G::LOGE>(v, t, xb);
       }
       constexpr bool PL = MODE == MODE_R2C && PAIRED;
-      if constexpr (TWO) wg_passes<LOGN, G::LOGE, 0, FWD, PL>(v, t, tab2, xb);
+      if constexpr (TWO && CLFA_LANE_SIGMA && FPW == 1) {
+        const int ts = lane_sigma(t);
+        const auto tab2s = [&]() {
+          if constexpr (LOGN == 14) return LaneTab14{s_tab + kRow16Stride * (ts & 15), s_tab + kRow16Lds + (ts & 255), wl[0], wl[1], wl[2]};
+          else return LaneTab13{s_tab + kRow16Stride * (ts & 15), s_tab + kRow16Lds + (ts & 255), wl[0]};
+        }();
+        wg_passes_sigma<LOGN, G::LOGE, 0, FWD, PL>(v, t, ts, tab2, tab2s, xb);
+      } else if constexpr (TWO) wg_passes<LOGN, G::LOGE, 0, FWD, PL>(v, t, tab2, xb);
       else wg_passes<LOGN, G::LOGE, 0, FWD, PL>(v, t, tab1, xb);
     }
 
@@ -507,8 +519,16 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
   constexpr int NTAB = LANE ? kLaneLds : M / 2;
   __shared__ cpx s_tab[NTAB];
   __shared__ cpx s_x[lds_padded_size(M)];
+  // eight points per lane (real size 8192): the tables of the passes that start at 8 and at 64 points (PassTabs)
+  constexpr bool PTABS = !LANE && LOGE == 3 && LOGC == 11;
+  constexpr int PT1 = pass_tab_size(3, 3), PT2 = pass_tab_size(6, 3);
+  __shared__ cpx s_pt[PTABS ? PT1 + PT2 : 1];
   const int tid = threadIdx.x;
   for (int i = tid; i < (LANE ? kLane13Lds : M / 2); i += T) s_tab[LANE ? lane_lds_index(i) : i] = tab_g[i];
+  if constexpr (PTABS) {
+    lds_fill_pass_tab<LOGC, 3, 3>(s_pt, tab_g, tid, T);
+    lds_fill_pass_tab<LOGC, 6, 3>(s_pt + PT1, tab_g, tid, T);
+  }
   // lane constants kept across the batch loop: W_M^tid and W_4M^tid only (4 VGPRs; the kernel runs under the 128-VGPR
   // cap) — W_M^(2 tid), ^(3 tid) and W_2M^tid are their products
   const cpx wl0 = LANE ? tab_g[kLane13Lds + tid] : mk(1.f, 0.f);
@@ -525,6 +545,8 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
         return LaneTab14{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0, wl1, cmul(wl0, wl1)};
       } else if constexpr (LOGC == 13) {
         return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0};
+      } else if constexpr (PTABS) {
+        return PassTabs<2>{s_tab, {s_pt + (t & 7), s_pt + PT1 + (t & 63)}};
       } else {
         return static_cast<const cpx *>(s_tab);
       }
@@ -542,7 +564,10 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
         vb[e] = mk(q.z, q.w);
       }
       pass_compute<LOGN, LOGE, 0, true>(va, t, tab);
-      wg_passes_pair<LOGN, LOGE, 0, true>(va, vb, t, tab, xb);   // staggered: one chain's LDS transfers under the other's passes
+      // staggered: one chain's LDS transfers under the other's passes.  (The middle passes on permuted lanes — fft_wg.hpp,
+      // wg_passes_pair_sigma, conflict-free gathers — measured nothing here: size 32768 +1.4 %, 65536 -0.5 %,
+      // profiles/ab_lane_sigma_r05.txt; the complex kernel below keeps them for its -0.7 %.)
+      wg_passes_pair<LOGN, LOGE, 0, true>(va, vb, t, tab, xb);
       if constexpr (SCALE) {
         constexpr float inv = 1.0f / (float)(2 * M);
 #pragma unroll
@@ -649,14 +674,15 @@ __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_cfft_2x(cpx *__restrict
   for (long b = blockIdx.x; b < batch; b += gridDim.x) {
     int t = tid;   // opaque per iteration: LDS / global offsets are recomputed, not kept live across the loop
     asm volatile("" : "+v"(t));
-    const auto tab = [&]() {
+    const auto tab_of = [&](int t) {
       if constexpr (LOGC == 14) {
         const cpx wl1 = cmul(wl0, wl0);
         return LaneTab14{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0, wl1, cmul(wl0, wl1)};
       } else {
         return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0};
       }
-    }();
+    };
+    const auto tab = tab_of(t);
     cpx *x = data + b * (long)(2 * M);
     cpx va[E], vb[E];
 #pragma unroll
@@ -666,7 +692,8 @@ __global__ __launch_bounds__((1 << LOGC) / 16, 4) void k_cfft_2x(cpx *__restrict
       vb[e] = mk(q.z, q.w);
     }
     pass_compute<LOGN, LOGE, 0, FWD>(va, t, tab);
-    wg_passes_pair<LOGN, LOGE, 0, FWD, false>(va, vb, t, tab, xb);
+    if constexpr (CLFA_LANE_SIGMA) wg_passes_pair_sigma<LOGN, LOGE, 0, FWD, false>(va, vb, t, lane_sigma(t), tab, tab_of(lane_sigma(t)), xb);
+    else wg_passes_pair<LOGN, LOGE, 0, FWD, false>(va, vb, t, tab, xb);
     // radix-2 step: position i = t + T e, W_2M^i = W_2M^t W_32^e
     constexpr float c32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
                                0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,

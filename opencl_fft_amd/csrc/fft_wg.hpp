@@ -25,6 +25,35 @@ __device__ __forceinline__ void wg_passes(cpx (&v)[1 << LOGE], int t, const Tab 
   }
 }
 
+// The same chain with the MIDDLE passes worked by permuted lanes (T >= 512 lanes: n = 8192, 16384).  A gather reads
+// positions L + T e, L = the lane's logical index; with L = tid the two 16-lane halves of a ds_read_b64 group read
+// neighbouring 16-blocks of the padded buffer, 34 dwords apart, and lane 31 falls on lane 0's banks — every gather costs
+// twice its LDS cycles (MI355X_MICROARCH.md: 32 lanes over 64 banks).  With L = sigma(tid) — bits 4 and 8 swapped — the
+// halves are 256 positions = 544 dwords = 32 (mod 64) apart: conflict-free.  Which lane works which butterfly is free
+// between the first pass (global loads: L = tid) and the last (global stores: L = tid), so the passes in between run on
+// L = sigma(tid) with the twiddle table of that lane (`tabs`); the scatters see sixteen consecutive logical lanes per
+// 16-lane write group either way.  Results are the plain chain's, value for value (tests/cpp/emulate_engine.cpp).
+template <int LOGN, int LOGE, int LOGNS, bool FWD, bool PAIRLAST = false, class Tab>
+__device__ __forceinline__ void wg_passes_sigma(cpx (&v)[1 << LOGE], int t, int ts, const Tab &tab, const Tab &tabs, cpx *xb) {
+  static_assert(LOGN - LOGE >= 9, "needs bit 8 of the lane index");
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS), NEXT = LOGNS + LOGR;
+  constexpr bool FIRST = LOGNS == 0, LAST = NEXT == LOGN;
+  // the first and the last pass belong to lane t, the others to lane ts
+  pass_compute<LOGN, LOGE, LOGNS, FWD>(v, (FIRST || LAST) ? t : ts, (FIRST || LAST) ? tab : tabs);
+  if constexpr (!LAST) {
+    constexpr bool NEXT_LAST = NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN;
+    __syncthreads();  // everybody is done reading the previous exchange
+    pass_scatter_padded<LOGN, LOGE, LOGNS>(v, FIRST ? t : ts, xb);
+    __syncthreads();
+    if constexpr (PAIRLAST && NEXT_LAST) {
+      pass_last_paired<LOGN, LOGE, FWD>(v, t, tab, xb);
+    } else {
+      pass_gather_padded<LOGN, LOGE>(v, NEXT_LAST ? t : ts, xb);
+      wg_passes_sigma<LOGN, LOGE, NEXT, FWD, PAIRLAST>(v, t, ts, tab, tabs, xb);
+    }
+  }
+}
+
 // the transposed chain from the pass (2^LOGNS, radix 2^LOGE) downwards; v holds what the pass
 // before it (a bigger LOGNS) has just computed, i.e. positions tid + T*e
 template <int LOGN, int LOGE, int LOGNS, bool FWD, class Tab>
@@ -72,6 +101,40 @@ __device__ __forceinline__ void wg_passes_pair(cpx (&va)[1 << LOGE], cpx (&vb)[1
     pass_gather_padded<LOGN, LOGE>(vb, t, xb);
     if constexpr (LAST) pass_compute<LOGN, LOGE, NEXT, FWD>(vb, t, tab);
     else wg_passes_pair<LOGN, LOGE, NEXT, FWD, PAIRLAST>(va, vb, t, tab, xb);
+  }
+}
+
+// ... with the middle passes on permuted lanes (wg_passes_sigma above): the pass that starts at 2^LOGNS belongs to lane
+// t if it is the first or the last of the chain, else to lane ts = lane_sigma(t) with that lane's tables `tabs`
+template <int LOGN, int LOGE, int LOGNS, bool FWD, bool PAIRLAST = true, class Tab>
+__device__ __forceinline__ void wg_passes_pair_sigma(cpx (&va)[1 << LOGE], cpx (&vb)[1 << LOGE], int t, int ts, const Tab &tab,
+                                                     const Tab &tabs, cpx *xb) {
+  static_assert(LOGN - LOGE >= 9, "needs bit 8 of the lane index");
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS), NEXT = LOGNS + LOGR;
+  static_assert(NEXT < LOGN, "at least one more pass");
+  constexpr bool LAST = NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN;   // the pass after this one is the last
+  const int tc = LOGNS == 0 ? t : ts, tn = LAST ? t : ts;            // owners of this pass and of the next
+  const Tab &tabc = LOGNS == 0 ? tab : tabs, &tabn = LAST ? tab : tabs;
+  __syncthreads();   // everybody is done reading the previous exchange
+  pass_scatter_padded<LOGN, LOGE, LOGNS>(va, tc, xb);
+  pass_compute<LOGN, LOGE, LOGNS, FWD>(vb, tc, tabc);          // under a's LDS writes
+  __syncthreads();
+  if constexpr (LAST && PAIRLAST) {
+    pass_last_paired<LOGN, LOGE, FWD>(va, t, tab, xb, [&]() {
+      __syncthreads();   // a's gather is complete in every wave
+      pass_scatter_padded<LOGN, LOGE, LOGNS>(vb, tc, xb);      // ... and b's writes run under a's last butterflies
+    });
+    __syncthreads();
+    pass_last_paired<LOGN, LOGE, FWD>(vb, t, tab, xb);
+  } else {
+    pass_gather_padded<LOGN, LOGE>(va, tn, xb);
+    __syncthreads();
+    pass_scatter_padded<LOGN, LOGE, LOGNS>(vb, tc, xb);
+    pass_compute<LOGN, LOGE, NEXT, FWD>(va, tn, tabn);         // under b's LDS writes
+    __syncthreads();
+    pass_gather_padded<LOGN, LOGE>(vb, tn, xb);
+    if constexpr (LAST) pass_compute<LOGN, LOGE, NEXT, FWD>(vb, tn, tabn);
+    else wg_passes_pair_sigma<LOGN, LOGE, NEXT, FWD, PAIRLAST>(va, vb, t, ts, tab, tabs, xb);
   }
 }
 

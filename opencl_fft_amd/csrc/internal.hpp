@@ -20,10 +20,7 @@ constexpr int kLane13Lds = 1280, kLane13Size = 1792;
 // sixteen DIFFERENT rows (row = tid & 15); 16 entries = 32 dwords apart they would fall on two groups of four banks (an
 // 8-way conflict, 32 LDS cycles per read — rocprofv3 round 4: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.41-0.46 for
 // config 3's kernel); 18 entries = 36 dwords apart they cover the 64 banks exactly once (MI355X_MICROARCH.md, LDS table)
-#ifndef CLFA_ROW16_STRIDE
-#define CLFA_ROW16_STRIDE 18
-#endif
-constexpr int kRow16Stride = CLFA_ROW16_STRIDE;
+constexpr int kRow16Stride = kRow16StrideDev;   // (fft_device.hpp: CLFA_ROW16_STRIDE)
 static_assert(kRow16Stride >= 16 && kRow16Stride % 2 == 0, "rows stay 16-byte aligned");
 constexpr int kRow16Lds = 16 * kRow16Stride;            // the s256 part follows
 constexpr int kLaneLds = kRow16Lds + (kLane13Lds - 256);   // entries of the LDS copy

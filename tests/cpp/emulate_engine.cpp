@@ -287,6 +287,47 @@ static void run_lane(std::vector<cpx> &regs, const std::vector<LT> &tabs, std::v
     }
   }
 }
+// fft_wg.hpp's wg_passes_sigma, lane by lane: registers slot `tid` is PHYSICAL lane tid; in the middle passes it works
+// butterfly lane_sigma(tid) with that lane's tables.  Also counts what the permutation is for: the bank conflicts of the
+// gathers' ds_read_b64 (two groups of 32 lanes over 64 banks of 4 bytes, MI355X_MICROARCH.md).
+static long g_conf_plain = 0, g_conf_sigma = 0;
+template <int LOGN> static long gather_conflicts(bool sigma) {
+  constexpr int T = (1 << LOGN) / 16;
+  long extra = 0;
+  for (int g = 0; g < T; g += 32) {
+    int cnt[64] = {0};
+    for (int l = g; l < g + 32; l++) {
+      const int L = sigma ? lane_sigma(l) : l, dw = 2 * lds_pad(L);
+      cnt[dw & 63]++;
+    }
+    int worst = 0;
+    for (int b = 0; b < 64; b++) worst = cnt[b] > worst ? cnt[b] : worst;
+    extra += worst - 1;
+  }
+  return extra;
+}
+template <int LOGN, int LOGNS, bool FWD, bool PAIRLAST, class LT>
+static void run_lane_sigma(std::vector<cpx> &regs, const std::vector<LT> &tabs, std::vector<cpx> &lds) {
+  constexpr int LOGE = 4, E = 16, T = 1 << (LOGN - LOGE);
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS), NEXT = LOGNS + LOGR;
+  constexpr bool FIRST = LOGNS == 0, LAST = NEXT == LOGN;
+  auto own = [&](int tid) { return (FIRST || LAST) ? tid : lane_sigma(tid); };
+  for (int tid = 0; tid < T; tid++)
+    pass_compute<LOGN, LOGE, LOGNS, FWD>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), own(tid), tabs[own(tid)]);
+  if constexpr (!LAST) {
+    constexpr bool NEXT_LAST = NEXT + pass_logr(LOGN, LOGE, NEXT) == LOGN;
+    for (int tid = 0; tid < T; tid++)
+      pass_scatter_padded<LOGN, LOGE, LOGNS>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), FIRST ? tid : lane_sigma(tid), lds.data());
+    if constexpr (PAIRLAST && NEXT_LAST) {
+      for (int tid = 0; tid < T; tid++)
+        pass_last_paired<LOGN, LOGE, FWD>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, tabs[tid], lds.data());
+    } else {
+      for (int tid = 0; tid < T; tid++)
+        pass_gather_padded<LOGN, LOGE>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), NEXT_LAST ? tid : lane_sigma(tid), lds.data());
+      run_lane_sigma<LOGN, NEXT, FWD, PAIRLAST>(regs, tabs, lds);
+    }
+  }
+}
 template <int LOGN, int LOGNS, class LT>
 static void run_lane_dif_inv(std::vector<cpx> &regs, const std::vector<LT> &tabs, std::vector<cpx> &lds) {
   constexpr int LOGE = 4, E = 16, T = 1 << (LOGN - LOGE);
@@ -354,6 +395,22 @@ template <int LOGN> static int lane_tables() {
   for (int i = 0; i < n; i++) if (seen[i] != 1) bad |= 2;
   const double e_pair = rel_l2(got, z);
   if (!(e_pair < 3e-7)) bad |= 4;
+  // the chain with its middle passes on permuted lanes: the same values in the same registers, and conflict-free gathers
+  {
+    std::vector<cpx> a(n), b(n);
+    for (int pl = 0; pl < 2; pl++)
+      for (int dir = 0; dir < 2; dir++) {
+        load(a, x); load(b, x);
+        if (pl && dir) { run_lane<LOGN, 0, true, true>(a, tabs, lds); run_lane_sigma<LOGN, 0, true, true>(b, tabs, lds); }
+        else if (pl) continue;   // (the paired last pass exists for forward transforms)
+        else if (dir) { run_lane<LOGN, 0, true, false>(a, tabs, lds); run_lane_sigma<LOGN, 0, true, false>(b, tabs, lds); }
+        else { run_lane<LOGN, 0, false, false>(a, tabs, lds); run_lane_sigma<LOGN, 0, false, false>(b, tabs, lds); }
+        for (int i = 0; i < n; i++) if (!(a[i].x == b[i].x && a[i].y == b[i].y)) bad |= 16;
+      }
+    const long cp = gather_conflicts<LOGN>(false), cs = gather_conflicts<LOGN>(true);
+    printf("n=2^%-2d gather bank conflicts (extra LDS cycles per gather instruction, all lane groups): lane = tid %ld, lane = sigma(tid) %ld\n", LOGN, cp, cs);
+    if (cs != 0 || cp == 0) bad |= 32;
+  }
   // inverse: pass_first_paired fed with natural-order data in pair order + transposed chain
   load(ref, x);
   run<LOGN, LOGE, 0, false>(ref, half, lds);
@@ -531,8 +588,79 @@ static int assignment() {
   return bad != 0;
 }
 
+// ---- the small per-pass twiddle tables (PassTabs: 2048 points, 8 per lane)
+// against the half table they are filled from: the same transform, value for value
+template <int LOGN, int LOGE, int LOGNS, bool FWD, class Mk>
+static void run_tab(std::vector<cpx> &regs, const Mk &mk_tab, std::vector<cpx> &lds) {
+  constexpr int E = 1 << LOGE, T = 1 << (LOGN - LOGE);
+  constexpr int LOGR = pass_logr(LOGN, LOGE, LOGNS);
+  for (int tid = 0; tid < T; tid++)
+    pass_compute<LOGN, LOGE, LOGNS, FWD>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, mk_tab(tid));
+  if constexpr (LOGNS + LOGR < LOGN) {
+    for (int tid = 0; tid < T; tid++)
+      pass_scatter_padded<LOGN, LOGE, LOGNS>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+    for (int tid = 0; tid < T; tid++)
+      pass_gather_padded<LOGN, LOGE>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+    run_tab<LOGN, LOGE, LOGNS + LOGR, FWD>(regs, mk_tab, lds);
+  }
+}
+// ... and the transposed chain (dif_compute), whose twiddles sit on the outputs
+template <int LOGN, int LOGE, int LOGNS, bool FWD, class Mk>
+static void run_tab_dif(std::vector<cpx> &regs, const Mk &mk_tab, std::vector<cpx> &lds) {
+  constexpr int E = 1 << LOGE, T = 1 << (LOGN - LOGE);
+  for (int tid = 0; tid < T; tid++)
+    dif_gather_padded<LOGN, LOGE, LOGNS>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+  for (int tid = 0; tid < T; tid++)
+    dif_compute<LOGN, LOGE, LOGNS, FWD>(*reinterpret_cast<cpx(*)[E]>(&regs[tid * E]), tid, mk_tab(tid));
+  if constexpr (LOGNS > 0) {
+    for (int tid = 0; tid < T; tid++)
+      dif_scatter_padded<LOGN, LOGE>(*reinterpret_cast<const cpx(*)[E]>(&regs[tid * E]), tid, lds.data());
+    run_tab_dif<LOGN, LOGE, LOGNS - LOGE, FWD>(regs, mk_tab, lds);
+  }
+}
+template <int LOGN, int LOGE> static int small_tables() {
+  constexpr int n = 1 << LOGN, E = 1 << LOGE, T = n / E;
+  std::vector<cpx> x(n), half(n / 2), a(n), b(n), lds(lds_padded_size(n));
+  unsigned s = 4242u + LOGN;
+  for (auto &c : x) {
+    s = s * 1664525u + 1013904223u; c.x = (float)(s >> 8) / 8388608.0f - 1.0f;
+    s = s * 1664525u + 1013904223u; c.y = (float)(s >> 8) / 8388608.0f - 1.0f;
+  }
+  const double PI = 3.141592653589793;
+  for (int i = 0; i < n / 2; i++) half[i] = mk((float)cos(i * 2 * PI / n), -(float)sin(i * 2 * PI / n));
+  std::vector<cpx> p1(pass_tab_size(LOGE, LOGE)), p2(pass_tab_size(2 * LOGE, LOGE));
+  lds_fill_pass_tab<LOGN, LOGE, LOGE>(p1.data(), half.data(), 0, 1);
+  lds_fill_pass_tab<LOGN, 2 * LOGE, LOGE>(p2.data(), half.data(), 0, 1);
+  auto plain = [&](int) { return static_cast<const cpx *>(half.data()); };
+  auto small = [&](int tid) { return PassTabs<2>{half.data(), {p1.data() + (tid & (E - 1)), p2.data() + (tid & (E * E - 1))}}; };
+  int bad = 0;
+  for (int dir = 0; dir < 2; dir++) {
+    for (int tid = 0; tid < T; tid++)
+      for (int e = 0; e < E; e++) a[tid * E + e] = b[tid * E + e] = x[tid + T * e];
+    if (dir) {
+      run_tab<LOGN, LOGE, 0, true>(a, plain, lds);
+      run_tab<LOGN, LOGE, 0, true>(b, small, lds);
+    } else {
+      run_tab<LOGN, LOGE, 0, false>(a, plain, lds);
+      run_tab<LOGN, LOGE, 0, false>(b, small, lds);
+    }
+    for (int i = 0; i < n; i++) bad += !(a[i].x == b[i].x && a[i].y == b[i].y);
+  }
+  if constexpr (LOGN % LOGE == 0) {   // the transposed chain from its last full-radix pass downwards (any data: both sides see the same)
+    constexpr int L0 = LOGN - LOGE;
+    for (int i = 0; i < n; i++) lds[lds_pad(i)] = x[i];
+    std::vector<cpx> l2 = lds;
+    run_tab_dif<LOGN, LOGE, L0, false>(a, plain, lds);
+    run_tab_dif<LOGN, LOGE, L0, false>(b, small, l2);
+    for (int i = 0; i < n; i++) bad += !(a[i].x == b[i].x && a[i].y == b[i].y);
+  }
+  printf("n=2^%-2d E=%-2d per-pass twiddle tables vs the half table: %d values differ\n", LOGN, E, bad);
+  return bad != 0;
+}
+
 int main() {
   g_fail |= assignment();
+  g_fail |= small_tables<11, 3>() | small_tables<9, 3>() | small_tables<12, 4>();
   both<1, 1>(); both<2, 2>(); both<3, 3>(); both<4, 4>(); both<5, 4>(); both<6, 4>(); both<7, 4>();
   both<8, 4>(); both<9, 4>(); both<10, 4>(); both<11, 4>(); both<12, 4>(); both<13, 4>(); both<14, 4>();
   both<6, 2>(); both<6, 3>(); both<10, 3>(); both<9, 2>(); both<7, 3>(); both<8, 3>();

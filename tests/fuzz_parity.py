@@ -140,7 +140,7 @@ def case_pconv():
         for c in range(channels):
             want[b, c] = os_[c].convolution(x1[b, c], x2[b, c]) if tv else os_[c].convolution(x1[b, c])
     check("pconv", "pts=%d parts=%d ch=%d %s %s blocks=%d kernel=%s" % (pts, nparts, channels, "tv" if tv else "static", "dev" if dev else "host", blocks, p.kernel_name()),
-          got, want, 3e-6)
+          got, want, max(1e-6, 1e-7 * float(np.sqrt(nparts))))   # float32 sums of nparts products in two orders: 3.5e-7 at 94 partitions (profiles/conv_accuracy_r05.txt)
 
 
 def case_dconv():
@@ -172,7 +172,7 @@ def case_dconv():
             assert d.convolution(out, x1[b], x2[b] if tv else None) == 0
             got[b] = out
     want = np.stack([o.convolution(x1[b], x2[b]) if tv else o.convolution(x1[b]) for b in range(blocks)])
-    tol = max(2e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24)
+    tol = max(1e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24)   # tests/test_gpu_conv.py dconv_tol()
     check("dconv", "irsize=%d vsize=%d %s %s blocks=%d" % (irsize, vsize, "tv" if tv else "static", "dev" if dev else "host", blocks), got, want, tol)
 
 

@@ -12,8 +12,18 @@ pytestmark = pytest.mark.gpu
 
 # The reference sums partitions with float CAS atomics in arbitrary order
 # (cl_conv_kernels.h:116-117); ours sums in ascending partition order in
-# registers.  Same tolerance as the spectra, applied to the time-domain output.
-CTOL = 2e-6
+# registers.  Same tolerance as the spectra (north_star's 1e-6), applied to the time-domain output: measured against a
+# float64 evaluation of the same formulas (tests/test_gpu_conv_accuracy.py, profiles/conv_accuracy_r05.txt) the HIP result
+# is 2.3e-7 off, the oracle 2.9e-7, the two 3.3-3.7e-7 apart at config 4's 94 partitions.
+CTOL = 1e-6
+
+
+def dconv_tol(irsize):
+    """HIP vs oracle for Cldconv: two float32 sums of `irsize` products in different orders (cl_dconv.cpp:32-43 leaves the
+    order to its atomics).  Against float64 the HIP sums (chunks, then a tree) stay at 3-5e-7 for every length while the
+    oracle's one-by-one sum grows like sqrt(irsize): 4.6e-7 at 1024 taps, 5.8e-6 at 96000, 1.6e-5 at 2^20 — the difference
+    between the two IS the oracle's rounding (profiles/conv_accuracy_r05.txt), which this bound follows."""
+    return max(1e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24)
 
 
 def _run(p, blocks, pts, in1, in2=None):
@@ -196,7 +206,7 @@ def test_dconv_vs_reference_over_ring_cycles(tag, irsize, vsize, tv):
     x2 = golden(tag + "_in2") if tv else None
     d = fa.Cldconv(0, irsize, vsize)
     assert d.get_cl_err() == 0 and d.push_ir(ir) == 0
-    tol = max(1e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24)   # the reference's CAS-atomic sum is order-dependent
+    tol = dconv_tol(irsize)   # the reference's CAS-atomic sum is order-dependent
     first = irsize // vsize + 1
     for b in range(x.size // vsize):
         sl = slice(b * vsize, (b + 1) * vsize)
@@ -216,7 +226,7 @@ def test_dconv_ring_wrap_vs_oracle(irsize, vsize, blocks):
     for b in range(blocks):
         out = np.zeros(vsize, np.float32)
         assert d.convolution(out, x[b * vsize:(b + 1) * vsize]) == 0
-        assert_parity(out, o.convolution(x[b * vsize:(b + 1) * vsize]), tol=5e-6, what="block %d" % b)
+        assert_parity(out, o.convolution(x[b * vsize:(b + 1) * vsize]), tol=dconv_tol(irsize), what="block %d" % b)
 
 
 @pytest.mark.parametrize("irsize,vsize,blocks,tv", [(96000, 64, 6, False), (5000, 100, 8, True), (3, 200, 4, False),
@@ -239,7 +249,7 @@ def test_dconv_device_resident_blocks_vs_oracle(irsize, vsize, blocks, tv):
         assert d.process_device(dout[b], dx1[sl], dx2[sl] if tv else None) == 0
     torch.cuda.synchronize()
     got = dout.cpu().numpy()
-    tol = max(2e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24)   # float32 sums of irsize terms in another order
+    tol = dconv_tol(irsize)
     for b in range(blocks):
         sl = slice(b * vsize, (b + 1) * vsize)
         want = o.convolution(x1[sl], x2[sl]) if tv else o.convolution(x1[sl])
@@ -290,7 +300,7 @@ def test_dconv_handoff_under_load():
         o.push_ir(ir)
         xs1, xs2 = x1.cpu().numpy(), x2.cpu().numpy()
         want = np.stack([o.convolution(xs1[b], xs2[b]) if tv else o.convolution(xs1[b]) for b in range(6)])
-        assert_parity(outs[1][:6].cpu().numpy(), want, tol=max(2e-6, 2 * float(np.sqrt(irsize)) * 2.0 ** -24), what="first blocks vs oracle")
+        assert_parity(outs[1][:6].cpu().numpy(), want, tol=dconv_tol(irsize), what="first blocks vs oracle")
 
 
 def test_dconv_time_varying_vs_oracle():
@@ -303,7 +313,7 @@ def test_dconv_time_varying_vs_oracle():
         sl = slice(b * vsize, (b + 1) * vsize)
         assert d.convolution(out, x1[sl], x2[sl]) == 0
         want = o.convolution(x1[sl], x2[sl])
-        assert np.max(np.abs(out - want)) <= 5e-6 * max(1e-3, np.max(np.abs(want)))
+        assert np.max(np.abs(out - want)) <= dconv_tol(irsize) * max(1e-3, np.max(np.abs(want)))
 
 
 def test_config4_full_size_properties():
@@ -338,7 +348,7 @@ def test_config4_full_size_properties():
     ir = ir_saved[perm].contiguous()
     y3 = run(x[:, perm].contiguous())
     ir = ir_saved
-    assert float((y3 - y[:, perm]).abs().max()) <= 2e-6 * float(y.abs().max())
+    assert float((y3 - y[:, perm]).abs().max()) <= CTOL * float(y.abs().max())
     ir_h, x_h, y_h = ir.cpu().numpy(), x.cpu().numpy(), y.cpu().numpy()
     for c in (0, 127, 255):
         o = oracle.Pconv(cvs, pts)

@@ -69,7 +69,7 @@ def test_pconv_time_varying_hip_at_least_as_accurate_as_oracle():
     assert d[0] <= 1e-6 and d[1] <= 1e-6, d
 
 
-@pytest.mark.parametrize("irsize,vsize", [(1024, 64), (96000, 500), (1 << 20, 4096)])
+@pytest.mark.parametrize("irsize,vsize", [(1024, 64), (96000, 500), (1 << 20, 1024)])
 def test_dconv_hip_at_least_as_accurate_as_oracle(irsize, vsize):
     """Cldconv (cl_dconv.cpp:32-43, 109-132): the last block after the delay line has filled, every output (64 of them at
     irsize 2^20) against float64 and against the oracle's arithmetic — float32 products added one by one in tap order, which
