@@ -48,7 +48,8 @@ bool pick_device(csnd::Csound *cs, int index, cl_device_id &id) {
 // ---- clfft / clrfft: k-rate array in, k-rate array out -------------------------------------
 template <bool REAL> struct FftOp : csnd::Plugin<1, 3> {
   cl_fft::Clcfft *plan;
-  csnd::AuxMem<float> work;   // np2 complex (clfft) or np2 reals (clrfft), zero padded
+  csnd::AuxMem<float> aux;    // np2 complex (clfft) or np2 reals (clrfft), zero padded — used if the plan has no pinned memory
+  float *work;                // the array every k-cycle's transform() runs on: page-locked memory of the plan, else `aux`
   uint32_t np2;
 
   int init() {
@@ -69,10 +70,15 @@ template <bool REAL> struct FftOp : csnd::Plugin<1, 3> {
       plan = nullptr;
       return csound->init_error(msg);
     }
-    work.allocate(csound, REAL ? np2 : 2 * np2);
-    // the one array every k-cycle's transform() runs on, for the life of the instance: pinned, so the transform needs no
-    // staging copies (a refusal is not an error: the calls then copy as the reference's do)
-    plan->pin_host(work.data(), sizeof(float) * (REAL ? np2 : 2 * np2));
+    // the one array every k-cycle's transform() runs on, for the life of the instance: taken from the plan (page-locked,
+    // seen by the device), so the transform needs no staging copies; it dies with the plan.  A refusal is not an error: the
+    // calls then run on Csound's own memory and copy, as the reference's do.
+    const uint32_t cap = REAL ? np2 : 2 * np2;
+    work = static_cast<float *>(plan->alloc_host(sizeof(float) * cap));
+    if (!work) {
+      aux.allocate(csound, cap);
+      work = aux.data();
+    }
     return OK;
   }
 
@@ -80,17 +86,18 @@ template <bool REAL> struct FftOp : csnd::Plugin<1, 3> {
     csnd::Vector<MYFLT> &in = inargs.vector_data<MYFLT>(0);
     csnd::Vector<MYFLT> &out = outargs.vector_data<MYFLT>(0);
     const uint32_t cap = REAL ? np2 : 2 * np2, n = std::min<uint32_t>(in.len(), cap);
-    std::fill(work.begin(), work.end(), 0.f);
+    std::fill(work, work + cap, 0.f);
     for (uint32_t k = 0; k < n; k++) work[k] = (float)in[k];
-    int err = plan->transform(reinterpret_cast<std::complex<float> *>(work.data()));
+    int err = plan->transform(reinterpret_cast<std::complex<float> *>(work));
     if (err != CL_SUCCESS) return csound->perf_error(cl_fft::cl_error_string(err), this);
     for (uint32_t k = 0; k < std::min<uint32_t>(out.len(), cap); k++) out[k] = (MYFLT)work[k];
     return OK;
   }
 
   int deinit() {
-    delete plan;
+    delete plan;   // (releases `work` with it)
     plan = nullptr;
+    work = nullptr;
     return OK;
   }
 };

@@ -45,10 +45,11 @@ class Clcfft {
   int transform_device(void *data, long batch, void *stream = 0);
   /** ... from src to dst (the reference's device side is out of place too: data1 -> data2) */
   int transform_device(const void *src, void *dst, long batch, void *stream);
-  /** extension: pin an array the caller keeps for the object's life; transform() calls on arrays inside it then run on that
-      memory directly (no staging copies).  Unpinned by unpin_host() or the destructor; do not free it before. */
-  int pin_host(void *ptr, size_t bytes);
-  int unpin_host(void *ptr);
+  /** extension: page-locked host memory from the object, for a caller that keeps one array for the object's life;
+      transform() calls on arrays inside it run on that memory directly (no staging copies).  NULL if the runtime refuses.
+      Lives until free_host() or the destructor. */
+  void *alloc_host(size_t bytes);
+  int free_host(void *ptr);
   /** Get setup error code */
   int get_error() { return cl_err; }
   /** Get compilation log (setup diagnostics here; nothing is JIT-compiled) */

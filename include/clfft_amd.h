@@ -103,21 +103,20 @@ CLFA_API int clfa_cfft_transform(clfa_fft *plan, float *c, long batch);
 CLFA_API int clfa_rfft_transform(clfa_fft *plan, float *c, float *r, long batch);
 /* Extension to the two host calls above, which replace the reference's blocking clEnqueueWriteBuffer / ReadBuffer around
  * every transform (cl_fft.cpp:155-158, 275-291): a caller that keeps ONE array for the plan's life (the Csound opcodes keep
- * one AuxMem buffer per instance, csound/opcode.cpp) pins it once; transform calls on arrays INSIDE a pinned range then run
- * on that memory directly — the kernels read and write it over PCIe, one pass each way, no staging copy (up to 8 MiB per
- * call and on the routes that touch source and destination once; otherwise the usual copies, by DMA).  Results are
- * bit-identical to the unpinned call.  The range stays pinned until unregister or destroy; the caller must not free it
- * before.  Overlapping a range already pinned, NULL or 0 bytes: CL_INVALID_VALUE; a refusal of the runtime comes back as
- * its CL-numbered code.  Real plans, out of place: both arrays must be pinned for the direct route. */
-CLFA_API int clfa_fft_host_register(clfa_fft *plan, void *ptr, size_t bytes);
-CLFA_API int clfa_fft_host_unregister(clfa_fft *plan, void *ptr);
+ * one buffer per instance, csound/opcode.cpp) takes it from the plan — page-locked host memory the device sees.  transform
+ * calls on arrays INSIDE such a buffer run on that memory directly: the kernels read and write it over PCIe, one pass each
+ * way, no staging copy (up to 8 MiB per call and on the routes that touch source and destination once; otherwise the usual
+ * copies, by DMA).  Results are bit-identical to the copying call.  The memory lives until clfa_fft_host_free or the plan's
+ * destruction.  Real plans, out of place: both arrays must come from the plan for the direct route.  (Pinning the caller's
+ * own heap array — hipHostRegister — was measured and is not offered: clfft_amd.cpp, profiles/host_path_r05.txt.) */
+CLFA_API int clfa_fft_host_alloc(clfa_fft *plan, size_t bytes, void **ptr);
+CLFA_API int clfa_fft_host_free(clfa_fft *plan, void *ptr);
 /* device-resident, in place, asynchronous on `stream`: the body of
  * Clcfft::fft() (cl_fft.cpp:138-151) / the kernel part of Clrfft::transform.
  * data: batch * n complex64 (c2c) or batch * size float32 (r2c, packed in place). */
 CLFA_API int clfa_fft_exec_dev(clfa_fft *plan, void *data, long batch, void *stream);
 /* the same from `src` to `dst` (extension).  The reference's device side is itself out of place — its `reorder` gathers
- * data1 -> data2 and the stages then run on data2, cl_fft.cpp:138-151 — and on MI355X a kernel that reads one buffer and
- * writes another is ~3 % faster than the same kernel in place for n = 65536.  Every plan runs
+ * data1 -> data2 and the stages then run on data2, cl_fft.cpp:138-151.  Every plan runs
  * src -> dst natively, at the cost of the in-place call: the kernels read the source and write the destination, routes of
  * several passes put their first pass there.  src == dst is clfa_fft_exec_dev; partly overlapping buffers, and buffers
  * that are not a whole number of complex values apart, are CLFA_INVALID_VALUE.  `src` is left untouched. */

@@ -119,20 +119,21 @@ class _Plan:
     def kernel_name(self):
         return lib().clfa_fft_kernel_name(self._h).decode()
 
-    def pin_host(self, array):
-        """extension (clfa_fft_host_register): pin a numpy array the caller keeps for the plan's life; transform() calls on
-        it (or on slices of it) then run on that memory directly, without staging copies"""
-        self._pinned = getattr(self, "_pinned", [])
-        e = lib().clfa_fft_host_register(self._h, array.ctypes.data, array.nbytes)
-        if e == 0:
-            self._pinned.append(array)      # keeps the memory alive while it is pinned
-        return e
+    def alloc_host(self, shape, dtype):
+        """extension (clfa_fft_host_alloc): a numpy array over page-locked host memory of the plan; transform() calls on it
+        (or on contiguous slices of it) run on that memory directly, without staging copies.  The array must not outlive the
+        plan; free_host(array) releases it earlier."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        ptr = C.c_void_p()
+        e = lib().clfa_fft_host_alloc(self._h, n * dt.itemsize, C.byref(ptr))
+        if e != CL_SUCCESS:
+            return None
+        buf = (C.c_char * (n * dt.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
 
-    def unpin_host(self, array):
-        e = lib().clfa_fft_host_unregister(self._h, array.ctypes.data)
-        if e == 0:
-            self._pinned = [a for a in getattr(self, "_pinned", []) if a is not array]
-        return e
+    def free_host(self, array):
+        return lib().clfa_fft_host_free(self._h, array.ctypes.data)
 
     def exec_device(self, data, batch, stream=None):
         """in place on device memory, asynchronous on `stream` (Clcfft::fft(), cl_fft.cpp:138-151)"""

@@ -31,8 +31,8 @@ SYMBOLS = [
     ("clfa_fft_get_log", C.c_char_p, [_vp]),
     ("clfa_cfft_transform", C.c_int, [_vp, _vp, C.c_long]),
     ("clfa_rfft_transform", C.c_int, [_vp, _vp, _vp, C.c_long]),
-    ("clfa_fft_host_register", C.c_int, [_vp, _vp, C.c_size_t]),
-    ("clfa_fft_host_unregister", C.c_int, [_vp, _vp]),
+    ("clfa_fft_host_alloc", C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    ("clfa_fft_host_free", C.c_int, [_vp, _vp]),
     ("clfa_fft_exec_dev", C.c_int, [_vp, _vp, C.c_long, _vp]),
     ("clfa_fft_exec_dev_oop", C.c_int, [_vp, _vp, _vp, C.c_long, _vp]),
     ("clfa_fft_device_buffers", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),

@@ -38,8 +38,11 @@ int Clcfft::transform_device(void *data, long batch, void *stream) { return clfa
 int Clcfft::transform_device(const void *src, void *dst, long batch, void *stream) {
   return clfa_fft_exec_dev_oop(plan, src, dst, batch, stream);
 }
-int Clcfft::pin_host(void *ptr, size_t bytes) { return clfa_fft_host_register(plan, ptr, bytes); }
-int Clcfft::unpin_host(void *ptr) { return clfa_fft_host_unregister(plan, ptr); }
+void *Clcfft::alloc_host(size_t bytes) {
+  void *ptr = NULL;
+  return clfa_fft_host_alloc(plan, bytes, &ptr) == CLFA_SUCCESS ? ptr : NULL;
+}
+int Clcfft::free_host(void *ptr) { return clfa_fft_host_free(plan, ptr); }
 const char *Clcfft::get_log() { return clfa_fft_get_log(plan); }
 
 Clrfft::Clrfft(cl_device_id device_id, int size, bool fwd) : Clcfft(device_id, size, fwd, true) {}   // cl_fft.cpp:208-259

@@ -261,7 +261,7 @@ struct clfa_fft {
   DevBuf own1, own2;     // the reference's protected data1 / data2 (cl_fft.h:35), on request: clfa_fft_device_buffers
   DevBuf own_w, own_b;   // ... and w / b: clfa_fft_device_tables
   bool own_tables_ready = false;   // both tables allocated AND filled
-  struct Pinned {          // a caller array pinned for the plan's life: clfa_fft_host_register
+  struct Pinned {          // a pinned array the caller got from the plan: clfa_fft_host_alloc
     char *h, *d;           // host address, and the same memory as the device sees it
     size_t bytes;
   };
@@ -479,7 +479,7 @@ static int blue_setup(clfa_fft *p, int device, int n, bool real, bool fwd) {
   if ((e = clfa_cfft_create(&p->blue_i, device, m, 0))) return e;
   // workspace: as many m-point rows as fit 256 MiB (at least one); exec walks the batch in such chunks
   const size_t per = sizeof(cpx) * (size_t)m, cap = (size_t)256 << 20;
-  if ((e = p->blue_work.ensure(per * (cap / per > 0 ? cap / per : 1)))) return e;
+  if (!blue_lds_ok(m) && (e = p->blue_work.ensure(per * (cap / per > 0 ? cap / per : 1)))) return e;   // (m <= 8192: one launch, no workspace)
   if (real) {
     std::vector<cpx> h;
     fill_w2(h, n, fwd ? -1.f : 1.f);
@@ -627,7 +627,7 @@ void clfa_fft_destroy(clfa_fft *p) {
     (void)hipStreamSynchronize(p->stream);
     (void)hipStreamDestroy(p->stream);
   }
-  for (auto &r : p->pinned) (void)hipHostUnregister(r.h);
+  for (auto &r : p->pinned) (void)hipHostFree(r.h);
   p->pinned.clear();
   if (p->own_cplx) clfa_fft_destroy(p->own_cplx);
   if (p->blue_f) clfa_fft_destroy(p->blue_f);
@@ -663,7 +663,7 @@ size_t clfa_fft_workspace_bytes(const clfa_fft *p) {
 const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
   if (p->logn > kMaxLog) return "k_big_cols";
-  if (p->blue_m) return "bluestein";
+  if (p->blue_m) return blue_lds_ok(p->blue_m) ? "k_blue_lds" : "bluestein";
   if (p->rlds15 || p->r2x13) return "k_rfft_2x";
   if (p->c2x13) return "k_cfft_2x";
   return p->logn <= kLdsMaxLog ? name_fft_lds(p->logn, p->fwd, !p->real ? MODE_C2C : (p->fwd ? MODE_R2C : MODE_C2R)) : name_fft_4step(p->logn);
@@ -683,6 +683,11 @@ static int fft_exec(clfa_fft *p, cpx *d, long off, long batch, hipStream_t s) {
     if (p->real && !p->fwd) {
       HIP_TRY(launch_c2r_unpack(d, p->tabs.w2, n, batch, s, off));   // -> the destination
       src = o;
+    }
+    if (blue_lds_ok(m)) {   // one launch, one read and one write of the data (fft_kernels.hip, k_blue_lds)
+      HIP_TRY(launch_blue_lds(m, src, o, w, bt, p->blue_f->tabs.half, n, (scale ? 1.0f / (float)n : 1.0f) / (float)m, batch, p->di, s));
+      if (p->real && p->fwd) HIP_TRY(launch_r2c_pack(o, p->tabs.w2, n, batch, s));
+      return CLFA_SUCCESS;
     }
     const long cb = (long)(p->blue_work.bytes / (sizeof(cpx) * (size_t)m));
     for (long b0 = 0; b0 < batch; b0 += cb) {
@@ -871,37 +876,41 @@ static long chunk_batches(size_t bytes_per_batch, long batch) {
   return c < batch ? c : batch;
 }
 
-// ---- caller arrays pinned for the plan's life (extension) ------------------------------------------------------
+// ---- pinned arrays for the caller (extension) --------------------------------------------------------------------
 // The reference's transform() copies the caller's array to the device and back with two blocking transfers
-// (cl_fft.cpp:155-158).  A caller that keeps ONE array for the object's life — the Csound opcodes do: one AuxMem
-// buffer per instance, csound/opcode.cpp — can pin it once: transform() calls on arrays inside a pinned range then
-// run on that memory directly (the kernels read and write it over PCIe, one pass each way, no staging copy, one
-// synchronisation).  Explicit on purpose: nothing tells the library that an address seen before is still the same
-// allocation, so nothing is pinned behind the caller's back.
-int clfa_fft_host_register(clfa_fft *p, void *ptr, size_t bytes) {
-  if (!p) return CLFA_INVALID_VALUE;
+// (cl_fft.cpp:155-158).  A caller that keeps ONE array for the object's life — the Csound opcodes do: one buffer per
+// instance, csound/opcode.cpp — can take that array FROM the plan: page-locked host memory mapped into the device's
+// address space.  transform() calls on arrays inside it run on that memory directly (the kernels read and write it over
+// PCIe, one pass each way, no staging copy, one synchronisation).
+// Why the plan allocates instead of pinning the caller's own array: hipHostRegister on heap arrays was built and measured
+// first (round 5) — with arrays registered, unregistered, freed and their addresses reused by arrays of other sizes it
+// produced wrong results in 8 of 3000 randomised calls and one GPU memory access fault on a host heap address
+// (tools/stress_pinned.py; profiles/host_path_r05.txt) although every array was unregistered before it was freed.
+// Memory of hipHostMalloc is the route the staging buffers have used since round 1.
+int clfa_fft_host_alloc(clfa_fft *p, size_t bytes, void **ptr) {
+  if (!p || !ptr) return CLFA_INVALID_VALUE;
+  *ptr = nullptr;
   if (p->err) return p->err;
-  if (!ptr || !bytes) return CLFA_INVALID_VALUE;
-  for (auto &r : p->pinned)
-    if ((char *)ptr < r.h + r.bytes && r.h < (char *)ptr + bytes) return CLFA_INVALID_VALUE;   // overlaps a pinned range
+  if (!bytes) return CLFA_INVALID_VALUE;
   ENTER_DEVICE(p->di.device);
-  void *d = nullptr;
-  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped);
-  if (e == hipSuccess && (e = hipHostGetDevicePointer(&d, ptr, 0)) != hipSuccess) (void)hipHostUnregister(ptr);
+  void *h = nullptr, *d = nullptr;
+  hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocMapped);
+  if (e == hipSuccess && (e = hipHostGetDevicePointer(&d, h, 0)) != hipSuccess) (void)hipHostFree(h);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return map_hip(e);
   }
-  p->pinned.push_back({(char *)ptr, (char *)d, bytes});
+  p->pinned.push_back({(char *)h, (char *)d, bytes});
+  *ptr = h;
   return CLFA_SUCCESS;
 }
-int clfa_fft_host_unregister(clfa_fft *p, void *ptr) {
+int clfa_fft_host_free(clfa_fft *p, void *ptr) {
   if (!p) return CLFA_INVALID_VALUE;
   for (size_t i = 0; i < p->pinned.size(); i++)
     if (p->pinned[i].h == (char *)ptr) {
       ENTER_DEVICE(p->di.device);
       if (p->stream) (void)hipStreamSynchronize(p->stream);
-      (void)hipHostUnregister(ptr);
+      (void)hipHostFree(ptr);
       p->pinned.erase(p->pinned.begin() + (long)i);
       return CLFA_SUCCESS;
     }
@@ -931,7 +940,7 @@ int clfa_cfft_transform(clfa_fft *p, float *c, long batch) {
   ENTER_DEVICE(p->di.device);
   const size_t per = sizeof(cpx) * (size_t)p->n;
   if (batch > 0 && per * (size_t)batch <= kPinnedZeroCopyMax && one_touch_route(p, batch)) {
-    if (void *dv = pinned_dev(p, c, per * (size_t)batch)) {   // the caller's own array, pinned: in place over PCIe
+    if (void *dv = pinned_dev(p, c, per * (size_t)batch)) {   // an array of clfa_fft_host_alloc: in place over PCIe
       // measured per call (profiles/host_path_r05.txt): up to 256 KiB the kernels read AND write the caller's memory
       // (N = 32768: 32.1 us; the copy engine in front costs 5, on both sides 11 more); above it the copy engine brings the
       // array in and the kernels write the caller's memory (N = 65536: 48.9 us against 52.7 both ways by the kernels, 52.6
@@ -981,7 +990,7 @@ int clfa_rfft_transform(clfa_fft *p, float *c, float *r, long batch) {
   if (batch > 0 && per * (size_t)batch <= kPinnedZeroCopyMax && one_touch_route(p, batch)) {
     void *src = p->fwd ? (void *)r : (void *)c, *dst = p->fwd ? (void *)c : (void *)r;
     void *ds = pinned_dev(p, src, per * (size_t)batch), *dd = src == dst ? ds : pinned_dev(p, dst, per * (size_t)batch);
-    if (ds && dd) {   // both of the caller's arrays pinned (or one, in place)
+    if (ds && dd) {   // both arrays (or the one, in place) come from clfa_fft_host_alloc
       const int e = clfa_fft_exec_dev_oop(p, ds, dd, batch, p->stream);
       if (e) return e;
       HIP_TRY(hipStreamSynchronize(p->stream));

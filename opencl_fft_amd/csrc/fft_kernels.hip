@@ -1803,6 +1803,94 @@ __global__ __launch_bounds__(256) void k_blue_post(const cpx *__restrict__ a, co
     x[g] = cscale(cmul(a[b * m + k], w[k]), scale);
   }
 }
+// Bluestein in ONE launch for m <= 8192 (n <= 4096): a transform's chirp multiply, m-point forward transform, multiply by
+// the chirp's spectrum, m-point inverse transform and second chirp multiply all happen in the registers + LDS of one
+// workgroup, on the pass chains of k_fft_lds (same tables: the m-point plan's) — one read and one write of the data where
+// the composed form (pre, plan, mul, plan, post) makes five passes over a zero-padded copy.  In place (x == y) is fine:
+// a transform is read completely before any of it is written.
+template <int LOGM>
+__global__ __launch_bounds__(LdsGeom<LOGM>::WG, LdsGeom<LOGM>::MIN_WAVES) void k_blue_lds(const cpx *__restrict__ x, cpx *__restrict__ y,
+                                                              const cpx *__restrict__ w, const cpx *__restrict__ bt,
+                                                              const cpx *__restrict__ tab_g, int n, float scale, long batch) {
+  using G = LdsGeom<LOGM>;
+  constexpr int M = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
+  static_assert(G::LOGE == 4 && LOGM >= 8 && LOGM <= 13, "16 points per lane");
+  constexpr bool TWO = kLdsTwoLevel(LOGM);
+  __shared__ cpx s_tab[TWO ? kLaneLds : G::HALF];
+  __shared__ cpx s_x[FPW * G::PADN];
+  const int tid = threadIdx.x;
+  const int f = FPW == 1 ? 0 : tid / T, t0 = FPW == 1 ? tid : tid % T;
+  for (int i = tid; i < (TWO ? kLane13Lds : M / 2); i += WG) s_tab[TWO ? lane_lds_index(i) : i] = tab_g[i];
+  cpx wl = mk(1.f, 0.f);
+  if constexpr (TWO) wl = tab_g[kLane13Lds + t0];
+  cpx *xb = s_x + f * G::PADN;
+  const long groups = (batch + FPW - 1) / FPW;
+  __syncthreads();
+#pragma unroll 1
+  for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+    int t = t0;   // opaque per iteration (see k_fft_lds)
+    asm volatile("" : "+v"(t));
+    const auto tab = [&]() {
+      if constexpr (TWO) return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl};
+      else return static_cast<const cpx *>(s_tab);
+    }();
+    long b = g * FPW + f;
+    b = b < batch ? b : batch - 1;   // lanes of a ragged last group redo the last transform (identical stores)
+    const cpx *xi = x + b * (long)n;
+    cpx v[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int j = t + T * e;
+      v[e] = j < n ? cmul(xi[j], w[j]) : mk(0.f, 0.f);
+    }
+    wg_passes<LOGM, 4, 0, true>(v, t, tab, xb);
+#pragma unroll
+    for (int e = 0; e < E; e++) v[e] = cmul(v[e], bt[t + T * e]);
+    wg_passes<LOGM, 4, 0, false>(v, t, tab, xb);
+    cpx *yo = y + b * (long)n;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int k = t + T * e;
+      if (k < n) yo[k] = cscale(cmul(v[e], w[k]), scale);
+    }
+  }
+}
+template <int LOGM>
+static hipError_t launch_blue_lds_m(const cpx *x, cpx *y, const cpx *w, const cpx *bt, const cpx *tab, int n, float scale,
+                                    long batch, const DeviceInfo &di, hipStream_t s) {
+  using G = LdsGeom<LOGM>;
+  const long groups = (batch + G::FPW - 1) / G::FPW;
+  static int occ = 0;
+  if (occ == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_blue_lds<LOGM>, G::WG, 0) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = 1;
+    }
+    occ = nb;
+  }
+  const long cap = (long)di.num_cus * occ;
+  const int grid = (int)(groups < cap ? groups : cap);
+  hipLaunchKernelGGL((k_blue_lds<LOGM>), dim3(grid < 1 ? 1 : grid), dim3(G::WG), 0, s, x, y, w, bt, tab, n, scale, batch);
+  return hipGetLastError();
+}
+bool blue_lds_ok(int m) { return m >= 256 && m <= 8192; }
+// x -> y (may be equal), batch transforms of n points; w = chirp (n), bt = its padded spectrum (m), tab = the m-point plan's
+// LDS table (FftTables::half); scale = the plan's output factor times 1 / m
+hipError_t launch_blue_lds(int m, const cpx *x, cpx *y, const cpx *w, const cpx *bt, const cpx *tab, int n, float scale,
+                           long batch, const DeviceInfo &di, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  switch (m) {
+    case 256: return launch_blue_lds_m<8>(x, y, w, bt, tab, n, scale, batch, di, s);
+    case 512: return launch_blue_lds_m<9>(x, y, w, bt, tab, n, scale, batch, di, s);
+    case 1024: return launch_blue_lds_m<10>(x, y, w, bt, tab, n, scale, batch, di, s);
+    case 2048: return launch_blue_lds_m<11>(x, y, w, bt, tab, n, scale, batch, di, s);
+    case 4096: return launch_blue_lds_m<12>(x, y, w, bt, tab, n, scale, batch, di, s);
+    case 8192: return launch_blue_lds_m<13>(x, y, w, bt, tab, n, scale, batch, di, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_blue_pre(const cpx *x, const cpx *w, cpx *a, int n, int m, long batch, hipStream_t s) {
   const long total = batch * m;
   hipLaunchKernelGGL(k_blue_pre, dim3(grid_for(total)), dim3(256), 0, s, x, w, a, n, m, total);

@@ -107,6 +107,9 @@ hipError_t launch_c2r_unpack(cpx *data, const cpx *w2, int m, long batch, hipStr
 // arbitrary (non power-of-two) complex lengths, an extension: Bluestein's algorithm around two m-point
 // power-of-two transforms, m >= 2 n - 1 (fft_kernels.hip); n up to kBlueMaxN
 constexpr int kBlueMaxN = 1 << 22;
+bool blue_lds_ok(int m);
+hipError_t launch_blue_lds(int m, const cpx *x, cpx *y, const cpx *w, const cpx *bt, const cpx *tab, int n, float scale,
+                           long batch, const DeviceInfo &di, hipStream_t s);
 hipError_t launch_blue_pre(const cpx *x, const cpx *w, cpx *a, int n, int m, long batch, hipStream_t s);
 hipError_t launch_blue_mul(cpx *a, const cpx *bt, int m, long batch, hipStream_t s);
 hipError_t launch_blue_post(const cpx *a, const cpx *w, cpx *x, int n, int m, float scale, long batch, hipStream_t s);

@@ -520,14 +520,19 @@ def test_cfft_big_sizes(logn, batch):
 # around two power-of-two plans gives the exact DFT of any length.  Yardstick: numpy's float64 FFT under the
 # reference's conventions, same norm-relative 1e-6 criterion.
 
-@pytest.mark.parametrize("n,batch", [(3, 7), (5, 1), (6, 3), (12, 100), (100, 33), (1000, 9), (1536, 5), (4095, 3), (4097, 2),
+@pytest.mark.parametrize("n,batch", [(3, 7), (5, 1), (6, 3), (12, 100), (100, 33), (129, 70), (300, 17), (1000, 9), (1536, 5),
+                                     (2049, 600), (4095, 3), (4096 - 7, 1), (4097, 2),
                                      (44100, 2), (48000, 3), (65537, 1), (100000, 2), (3 << 20, 1)])
 def test_cfft_any_length(n, batch):
+    """(convolution lengths 256 .. 8192, i.e. n = 65 .. 4096, run in ONE launch: k_blue_lds; ragged groups, more transforms
+    than workgroups)"""
     rng = np.random.default_rng(n)
     x = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
     f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
     assert f.get_error() == 0 and i.get_error() == 0, (f.get_log(), i.get_log())
-    assert f.kernel_name() == "bluestein" and f.workspace_bytes() > 0
+    m = 1 << int(np.ceil(np.log2(2 * n - 1)))
+    assert f.kernel_name() == ("k_blue_lds" if 256 <= m <= 8192 else "bluestein")
+    assert (f.workspace_bytes() > 0) == (f.kernel_name() == "bluestein")
     y = x.copy()
     assert f.transform(y) == 0
     assert_parity(y, (np.fft.fft(x.astype(np.complex128), axis=-1) / n).astype(np.complex64), what="fwd n=%d" % n)

@@ -253,44 +253,55 @@ def test_plan_survives_a_destroyed_caller_stream():
     assert_parity(y, oracle.cfft(x[:3], True), what="host call after stream destroy")
 
 
-def test_pinned_host_arrays_bit_identical():
-    """clfa_fft_host_register (extension): transform() on a caller array pinned for the plan's life runs on that memory
-    directly; results are bit-identical to the copying call (the reference's, cl_fft.cpp:153-161, 267-296), for one transform
-    and for a batch, complex and packed real (in place, and out of place with both arrays pinned); errors; unpinning"""
+def test_plan_host_arrays_bit_identical():
+    """clfa_fft_host_alloc (extension): transform() on an array the caller took from the plan (page-locked, seen by the
+    device) runs on that memory directly; results are bit-identical to the copying call (the reference's, cl_fft.cpp:153-161,
+    267-296), for one transform and for a batch, complex and packed real (in place, and out of place with both arrays from
+    the plan), repeated with arrays coming and going; errors"""
     rng = np.random.default_rng(3)
-    for n, batch in ((65536, 1), (1024, 1), (65536, 3), (8192, 5)):
-        x = (rng.random((batch, n, 2), dtype=np.float32) * 2 - 1).view(np.complex64).reshape(batch, n)
-        for fwd in (True, False):
-            p = fa.Clcfft(0, n, fwd)
-            want = x.copy()
-            assert p.transform(want) == 0                      # the copying route
-            buf = np.zeros((batch + 1, n), np.complex64)       # the transform sits INSIDE the pinned range
-            assert p.pin_host(buf) == 0
-            assert p.pin_host(buf[1:]) == -30                  # overlaps a pinned range
-            buf[1:] = x
-            assert p.transform(buf[1:]) == 0
-            assert np.array_equal(buf[1:].view(np.uint32), want.view(np.uint32)), (n, batch, fwd)
-            assert np.all(buf[0] == 0)
-            assert p.unpin_host(buf) == 0 and p.unpin_host(buf) == -30
-            buf[1:] = x
-            assert p.transform(buf[1:]) == 0                   # ... and copies again afterwards
-            assert np.array_equal(buf[1:].view(np.uint32), want.view(np.uint32))
-    for size, batch in ((16384, 1), (16384, 4), (131072, 1)):
-        r = (rng.random((batch, size), dtype=np.float32) * 2 - 1)
-        f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
-        spec = np.zeros((batch, size // 2), np.complex64)
-        assert f.transform(spec, r.copy()) == 0
-        back = np.zeros((batch, size), np.float32)
-        assert i.transform(spec.copy(), back) == 0
-        # in place on one pinned array (the opcode's use)
-        a = r.copy()
-        assert f.pin_host(a) == 0
-        assert f.transform(a.view(np.complex64), a) == 0
-        assert np.array_equal(a.view(np.uint32), spec.view(np.uint32).reshape(batch, size))
-        # out of place, both arrays pinned
-        s2, b2 = spec.copy(), np.zeros((batch, size), np.float32)
-        assert i.pin_host(s2) == 0 and i.pin_host(b2) == 0
-        assert i.transform(s2, b2) == 0
-        assert np.array_equal(b2.view(np.uint32), back.view(np.uint32))
-        assert np.array_equal(s2, spec)                        # the source is left as it was
-    assert fa.Clcfft(0, 64, True).pin_host(np.zeros(0, np.complex64)) == -30
+    for rep in range(3):
+        for n, batch in ((65536, 1), (1024, 1), (65536, 3), (8192, 5), (4096, 6)):
+            x = (rng.random((batch, n, 2), dtype=np.float32) * 2 - 1).view(np.complex64).reshape(batch, n)
+            for fwd in (True, False):
+                p = fa.Clcfft(0, n, fwd)
+                want = x.copy()
+                assert p.transform(want) == 0                      # the copying route
+                buf = p.alloc_host((batch + 1, n), np.complex64)   # the transform sits INSIDE the plan's buffer
+                assert buf is not None
+                buf[0] = 0
+                buf[1:] = x
+                assert p.transform(buf[1:]) == 0
+                assert np.array_equal(buf[1:].view(np.uint32), want.view(np.uint32)), (n, batch, fwd)
+                assert np.all(buf[0] == 0)
+                other = p.alloc_host((batch, n), np.complex64)     # a second buffer of the same plan
+                other[:] = x
+                assert p.transform(other) == 0 and np.array_equal(other.view(np.uint32), want.view(np.uint32))
+                assert p.free_host(buf) == 0 and p.free_host(buf) == -30
+                del buf
+                y = x.copy()
+                assert p.transform(y) == 0 and np.array_equal(y.view(np.uint32), want.view(np.uint32))   # copies as before
+        for size, batch in ((16384, 1), (16384, 4), (16384, 3), (8192, 6), (131072, 1)):
+            r = (rng.random((batch, size), dtype=np.float32) * 2 - 1)
+            f, i = fa.Clrfft(0, size, True), fa.Clrfft(0, size, False)
+            spec = np.zeros((batch, size // 2), np.complex64)
+            assert f.transform(spec, r.copy()) == 0
+            back = np.zeros((batch, size), np.float32)
+            assert i.transform(spec.copy(), back) == 0
+            # in place on one array of the plan (the opcode's use)
+            a = f.alloc_host((batch, size), np.float32)
+            a[:] = r
+            assert f.transform(a.view(np.complex64), a) == 0
+            assert np.array_equal(a.view(np.uint32), spec.view(np.uint32).reshape(batch, size))
+            # out of place, both arrays from the plan
+            s2, b2 = i.alloc_host((batch, size // 2), np.complex64), i.alloc_host((batch, size), np.float32)
+            s2[:] = spec
+            b2[:] = 0
+            assert i.transform(s2, b2) == 0
+            assert np.array_equal(b2.view(np.uint32), back.view(np.uint32)), (size, batch)
+            assert np.array_equal(s2, spec)                        # the source is left as it was
+            # one array from the plan, the other the caller's own: the copying route, same result
+            b3 = np.zeros((batch, size), np.float32)
+            assert i.transform(s2, b3) == 0 and np.array_equal(b3.view(np.uint32), back.view(np.uint32))
+    p = fa.Clcfft(0, 64, True)
+    assert p.alloc_host((0,), np.complex64) is None
+    assert p.free_host(np.zeros(4, np.complex64)) == -30

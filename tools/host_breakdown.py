@@ -35,16 +35,16 @@ for n in (65536, 16384, 4096):
         s.synchronize()
         h.copy_(hp)
     x = np.zeros((1, n), np.complex64)
-    xp = np.zeros((1, n), np.complex64)
     g = fa.Clcfft(0, n, True)
-    assert g.pin_host(xp) == 0
+    xp = g.alloc_host((1, n), np.complex64)
+    xp[:] = 0
     print("N = %d (%d KiB each way)" % (n, n * 8 // 1024))
     print("  launch + stream sync (device-resident)      : %6.1f us" % t(launch_sync))
     print("  H2D pageable + sync / pinned + sync         : %6.1f / %6.1f us" % (t(h2d_page), t(h2d_pin)))
     print("  D2H pageable + sync / pinned + sync         : %6.1f / %6.1f us" % (t(d2h_page), t(d2h_pin)))
     print("  memcpy -> pinned staging, DMA, kernel, DMA, memcpy back (torch) : %6.1f us" % t(pinned_staging))
     print("  Clcfft.transform, caller's pageable array (library route)        : %6.1f us" % t(lambda: f.transform(x)))
-    print("  Clcfft.transform, caller's array pinned once (pin_host)          : %6.1f us" % t(lambda: g.transform(xp)))
+    print("  Clcfft.transform, array taken from the plan (alloc_host)         : %6.1f us" % t(lambda: g.transform(xp)))
     for path in sys.argv[1:]:
         lib = C.CDLL(path)
         for sym, res, args in L.SYMBOLS:
