@@ -305,3 +305,14 @@ def test_plan_host_arrays_bit_identical():
     p = fa.Clcfft(0, 64, True)
     assert p.alloc_host((0,), np.complex64) is None
     assert p.free_host(np.zeros(4, np.complex64)) == -30
+
+
+def test_plan_host_arrays_randomised():
+    """tools/stress_pinned.py with a fixed seed: arrays of random sizes taken from the plans and given back in a churning heap,
+    complex and packed real, in place and out of place, every result bit for bit what the device-resident call gives (the
+    stress that the first form of the feature — the caller's own arrays pinned in place — did not survive)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_pinned", os.path.join(ROOT, "tools", "stress_pinned.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(400, seed=5, verbose=False) == 0
