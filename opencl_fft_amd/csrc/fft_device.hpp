@@ -420,32 +420,29 @@ struct LaneTab14 {
 #define CLFA_ROW16_STRIDE 18
 #endif
 constexpr int kRow16StrideDev = CLFA_ROW16_STRIDE;
-// The eight-points-per-lane chains (packed real size 8192: two 2048-point runs, passes 8 x 8 x 8 x 4) take the
-// twiddles of the passes that start at 8 and at 64 points from tables of their own in [t][j] order — entry (t, j) =
-// W_(NS R)^(j t) at (t - 1) NS + j, j = tid & (NS - 1) — so that neighbouring lanes read neighbouring entries; in the half
-// table they are 64 t (NS = 8) and 8 t (NS = 64) dwords apart: 8- and 4..16-way conflicts on every read.
-template <int NP> struct PassTabs {
-  const cpx *half;     // LDS: W_n^k, k < n / 2 (the remainder pass and the pair maps)
-  const cpx *p[NP];    // LDS: table of the pass that starts at 2^((k + 1) LOGE) points, at the lane's j
+// Half table plus the 16 x 16 table W_256^(j t) for the pass that starts at 16 points: that pass's twiddles are
+// W_n^(j t n / 256) = W_256^(j t) whatever n is, j = tid & 15 — read from the half table they sit t n / 128 dwords apart
+// between neighbouring lanes (n = 4096: 32 t, two bank groups for sixteen addresses, an 8-way conflict on every read);
+// row j of the small table, rows kRow16StrideDev (18) entries apart, is conflict-free and needs no index arithmetic.  The
+// entries are the half table's own values (lds_fill_row16), so results do not change by a bit.  Used by the packed real
+// kernels of size 8192 (n = 4096: -5 %); for the complex kernels and the smaller sizes it measured between -1.3 and +2.2 %
+// (profiles/ab_small_twiddle_tables_r05.txt) and is not used.
+struct HalfRowTab {
+  const cpx *half;    // LDS: W_n^k, k < n / 2
+  const cpx *row16;   // LDS: row (tid & 15) of W_256^(j t)
 };
-template <class Tab> struct pass_tabs_count : std::integral_constant<int, 0> {};
-template <int NP> struct pass_tabs_count<PassTabs<NP>> : std::integral_constant<int, NP> {};
-template <int LOGN, bool FWD, int NP> CLFA_HD cpx cmul_tw(cpx v, const PassTabs<NP> &tab, int k) { return cmul_tw<LOGN, FWD>(v, tab.half, k); }
-constexpr int pass_tab_size(int logns, int logr) { return ((1 << logr) - 1) << logns; }
-template <int LOGN, int LOGNS, int LOGR> CLFA_HD void lds_fill_pass_tab(cpx *dst, const cpx *half_g, int tid, int nthreads) {
-  constexpr int N = 1 << LOGN, NS = 1 << LOGNS;
-  for (int i = tid; i < pass_tab_size(LOGNS, LOGR); i += nthreads) {
-    const int t = (i >> LOGNS) + 1, j = i & (NS - 1);
-    const int e = ((j * t) << (LOGN - LOGNS - LOGR)) & (N - 1);
+template <class Tab> struct has_row16 : std::false_type {};
+template <> struct has_row16<HalfRowTab> : std::true_type {};
+template <int LOGN, bool FWD> CLFA_HD cpx cmul_tw(cpx v, const HalfRowTab &tab, int k) { return cmul_tw<LOGN, FWD>(v, tab.half, k); }
+// fills the 16 x 16 table from the half table W_n^k (k < n / 2, forward sign) of an n-point transform, n >= 256
+template <int LOGN> CLFA_HD void lds_fill_row16(cpx *row, const cpx *half_g, int tid, int nthreads) {
+  static_assert(LOGN >= 8, "the pass that starts at 16 points has radix 16 from n = 256 on");
+  constexpr int N = 1 << LOGN;
+  for (int i = tid; i < 256; i += nthreads) {
+    const int e = ((i >> 4) * (i & 15) * (N / 256)) & (N - 1);
     const cpx w = half_g[e & (N / 2 - 1)];
-    dst[i] = e & (N / 2) ? mk(-w.x, -w.y) : w;
+    row[(i >> 4) * kRow16StrideDev + (i & 15)] = e & (N / 2) ? mk(-w.x, -w.y) : w;
   }
-}
-// v[t] times the pass table's entry t (radix = points per lane: one butterfly per lane)
-template <int LOGNS, int R, bool FWD> CLFA_HD void pass_tab_tw(cpx (&v)[R], const cpx *pt) {
-  v[1] = cmulc<!FWD>(v[1], pt[0]);
-#pragma unroll
-  for (int t = 2; t < R; t += 2) cmulc2<!FWD>(v[t], v[t + 1], v[t], pt[(t - 1) << LOGNS], v[t + 1], pt[t << LOGNS]);
 }
 template <class Tab> struct is_lane_tab : std::false_type {};
 template <> struct is_lane_tab<LaneTab13> : std::true_type {};
@@ -514,8 +511,8 @@ CLFA_HD void pass_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
   if constexpr (LOGNS > 0 && is_lane_tab<Tab>::value) {
     static_assert((LOGN == 13 || LOGN == 14) && LOGE == 4, "lane tables exist for 8192 and 16384 points");
     lane_tw<LOGNS, FWD>(v, tab);
-  } else if constexpr (LOGNS > 0 && LOGR == LOGE && LOGNS % LOGE == 0 && LOGNS / LOGE <= pass_tabs_count<Tab>::value) {
-    pass_tab_tw<LOGNS, E, FWD>(v, tab.p[LOGNS / LOGE - 1]);
+  } else if constexpr (LOGNS == 4 && LOGR == 4 && LOGE == 4 && has_row16<Tab>::value) {
+    lane_tw13<4, FWD>(v, LaneTab13{tab.row16, nullptr, mk(1.f, 0.f)});
   } else if constexpr (LOGNS > 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -616,8 +613,8 @@ CLFA_HD void dif_compute(cpx (&v)[1 << LOGE], int tid, const Tab &tab) {
   for (int u = 0; u < U; u++) dft<LOGR, U, E, FWD>(v, u);
   if constexpr (LOGNS > 0 && is_lane_tab<Tab>::value) {
     lane_tw<LOGNS, FWD>(v, tab);
-  } else if constexpr (LOGNS > 0 && LOGR == LOGE && LOGNS % LOGE == 0 && LOGNS / LOGE <= pass_tabs_count<Tab>::value) {
-    pass_tab_tw<LOGNS, E, FWD>(v, tab.p[LOGNS / LOGE - 1]);
+  } else if constexpr (LOGNS == 4 && LOGR == 4 && LOGE == 4 && has_row16<Tab>::value) {
+    lane_tw13<4, FWD>(v, LaneTab13{tab.row16, nullptr, mk(1.f, 0.f)});
   } else if constexpr (LOGNS > 0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {

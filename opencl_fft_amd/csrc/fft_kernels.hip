@@ -182,10 +182,20 @@ __device__ __forceinline__ void lds_fft_load(cpx (&v)[LdsGeom<LOGN>::E], const c
 #ifndef CLFA_LANE_SIGMA
 #define CLFA_LANE_SIGMA 1   // n = 8192: the middle passes on permuted lanes (fft_wg.hpp, wg_passes_sigma): conflict-free gathers
 #endif
+// hipcc pairs neighbouring ds_read_b64 / ds_write_b64 into ds_read2(st64)_b64 / ds_write2_b64, which the LDS serves at half
+// the bytes per clock (MI355X_MICROARCH.md, LDS table; fft_resident.hip has the whole story).  Kernels marked CLFA_DS_SINGLE_FN
+// are compiled without that pass.  It is a property of the FUNCTION, not of an instantiation, and pays for some
+// instantiations only (profiles/ab_ds_single_r05.txt: n = 32768 -2.0 %, packed real 32768 -1.3 .. -1.5 %, real 16384 0 .. -0.9 %;
+// complex 8192 +2.1 %, 1024 +2.0 %, real 65536 +3.3 %): k_fft_4step has it, k_rfft_2x exists as one body and two kernels
+// (`_s`: single LDS accesses, real size 32768), k_fft_lds and k_cfft_2x stay paired.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CLFA_DS_SINGLE_FN __attribute__((target("no-load-store-opt")))
+#else
+#define CLFA_DS_SINGLE_FN
+#endif
 template <int LOGN, bool FWD, int MODE, bool SCALE>
-__global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k_fft_lds(cpx *__restrict__ data,
-                                                              const cpx *__restrict__ tab_g,
-                                                              const cpx *__restrict__ w2_g, long batch, long out_off) {
+__device__ __forceinline__ void fft_lds_body(cpx *__restrict__ data, const cpx *__restrict__ tab_g, const cpx *__restrict__ w2_g,
+                                             long batch, long out_off) {
   // out_off: results go to data + out_off (complex elements; 0 = in place, else a disjoint destination: clfa_fft_exec_dev_oop)
   using G = LdsGeom<LOGN>;
   constexpr int N = G::N, E = G::E, T = G::T, WG = G::WG, FPW = G::FPW;
@@ -195,6 +205,9 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   constexpr int NTAB = TWO ? kLaneLds : G::HALF;
   __shared__ cpx s_tab[NTAB];
   __shared__ cpx s_x[FPW * G::PADN];
+  // packed real size 8192 (n = 4096): the twiddles of the pass that starts at 16 points from a 16 x 16 table (HalfRowTab)
+  constexpr bool ROW16 = !TWO && LOGN == 12 && MODE != MODE_C2C;
+  __shared__ cpx s_row[ROW16 ? kRow16Lds : 1];
 
   const int tid = threadIdx.x;
   const int f = FPW == 1 ? 0 : tid / T, t = FPW == 1 ? tid : tid % T;   // (FPW == 1: the base stays provably uniform)
@@ -227,6 +240,7 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
     lds_fft_load<LOGN, MODE, FWD>(v, data + (b < batch ? b : batch - 1) * (long)N, t);
   }
   for (int i = tid; i < (TWO ? kLane13Lds : N / 2); i += WG) s_tab[TWO ? lane_lds_index(i) : i] = tab_g[i];
+  if constexpr (ROW16) lds_fill_row16<LOGN>(s_row, tab_g, tid, WG);
   cpx *xb = s_x + f * G::PADN;
   // the lane's own twiddle constants: W_8192^t (n = 8192); W_16384^t, ^(2 t), ^(3 t) (n = 16384)
   cpx wl[LOGN == 14 ? 3 : 1];
@@ -304,9 +318,10 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
       if constexpr (LOGN == 14) return LaneTab14{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl[0], wl[1], wl[2]};
       else return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl[0]};
     }();
-    // (n = 256 .. 4096 with a 16 x 16 table for the pass that starts at 16 points — the lane tables' first part — was
-    // measured: -0.2 .. -1.3 % at n <= 2048, +2.2 % at n = 4096, profiles/ab_small_twiddle_tables_r05.txt: not kept)
-    const cpx *tab1 = s_tab;
+    const auto tab1 = [&]() {
+      if constexpr (ROW16) return HalfRowTab{s_tab, s_row + kRow16Stride * (t & 15)};
+      else return static_cast<const cpx *>(s_tab);
+    }();
     const long b = g * FPW + f;
     const bool active = b < batch;
     cpx *x = data + (active ? b : batch - 1) * (long)N;
@@ -464,6 +479,13 @@ __global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k
   }
 }
 
+template <int LOGN, bool FWD, int MODE, bool SCALE>
+__global__ __launch_bounds__(LdsGeom<LOGN>::WG, LdsGeom<LOGN>::MIN_WAVES) void k_fft_lds(cpx *__restrict__ data,
+                                                              const cpx *__restrict__ tab_g,
+                                                              const cpx *__restrict__ w2_g, long batch, long out_off) {
+  fft_lds_body<LOGN, FWD, MODE, SCALE>(data, tab_g, w2_g, batch, out_off);
+}
+
 // ---------------------------------------------------------------------------------
 // packed real size 65536 (n = 32768 complex): two runs of the 16384-point LDS machinery per transform
 // ---------------------------------------------------------------------------------
@@ -509,26 +531,18 @@ __device__ __forceinline__ void st_nt16(cpx *p, f4v v) {
 // k_rfft_2x<14>: real size 65536, one 1024-lane workgroup per CU (formerly k_rfft_lds15);
 // k_rfft_2x<13>: real size 32768, 512 lanes and 71 KiB of LDS — TWO workgroups per CU, which overlap each other's
 // memory phases (k_fft_lds<14> with its pair maps puts one 1024-lane workgroup on a CU)
-// k_rfft_2x<11, 3>: real size 8192 on two 2048-point runs with EIGHT points per lane (passes 8 x 8 x 8 x 4: the remainder
-// pass pairs, which no 16-point-per-lane form of a 4096-point transform does), 256 lanes, the half table in LDS
+// (the template also instantiates as <11, true | false, ., 3> — real size 8192 on two 2048-point runs with eight points per
+// lane, the half table in LDS; measured slower than k_fft_lds<12> in round 4 and without a launcher since)
 template <int LOGC, bool FWD, bool SCALE, int LOGE = 4>
-__global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
-                                                                    const cpx *__restrict__ w2_g, long batch, long out_off) {
+__device__ __forceinline__ void rfft_2x_body(cpx *__restrict__ data, const cpx *__restrict__ tab_g, const cpx *__restrict__ w2_g,
+                                             long batch, long out_off) {
   constexpr int LOGN = LOGC, E = 1 << LOGE, M = 1 << LOGC, T = M / E, R = 1 << pass_rem_logr(LOGC, LOGE);
   constexpr bool LANE = kLdsTwoLevel(LOGC);   // lane-addressed tables (8192 / 16384 points) or the half table W_M^k
   constexpr int NTAB = LANE ? kLaneLds : M / 2;
   __shared__ cpx s_tab[NTAB];
   __shared__ cpx s_x[lds_padded_size(M)];
-  // eight points per lane (real size 8192): the tables of the passes that start at 8 and at 64 points (PassTabs)
-  constexpr bool PTABS = !LANE && LOGE == 3 && LOGC == 11;
-  constexpr int PT1 = pass_tab_size(3, 3), PT2 = pass_tab_size(6, 3);
-  __shared__ cpx s_pt[PTABS ? PT1 + PT2 : 1];
   const int tid = threadIdx.x;
   for (int i = tid; i < (LANE ? kLane13Lds : M / 2); i += T) s_tab[LANE ? lane_lds_index(i) : i] = tab_g[i];
-  if constexpr (PTABS) {
-    lds_fill_pass_tab<LOGC, 3, 3>(s_pt, tab_g, tid, T);
-    lds_fill_pass_tab<LOGC, 6, 3>(s_pt + PT1, tab_g, tid, T);
-  }
   // lane constants kept across the batch loop: W_M^tid and W_4M^tid only (4 VGPRs; the kernel runs under the 128-VGPR
   // cap) — W_M^(2 tid), ^(3 tid) and W_2M^tid are their products
   const cpx wl0 = LANE ? tab_g[kLane13Lds + tid] : mk(1.f, 0.f);
@@ -545,8 +559,6 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
         return LaneTab14{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0, wl1, cmul(wl0, wl1)};
       } else if constexpr (LOGC == 13) {
         return LaneTab13{s_tab + kRow16Stride * (t & 15), s_tab + kRow16Lds + (t & 255), wl0};
-      } else if constexpr (PTABS) {
-        return PassTabs<2>{s_tab, {s_pt + (t & 7), s_pt + PT1 + (t & 63)}};
       } else {
         return static_cast<const cpx *>(s_tab);
       }
@@ -628,6 +640,18 @@ __global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restr
   }
 }
 
+template <int LOGC, bool FWD, bool SCALE, int LOGE = 4>
+__global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) void k_rfft_2x(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
+                                                                    const cpx *__restrict__ w2_g, long batch, long out_off) {
+  rfft_2x_body<LOGC, FWD, SCALE, LOGE>(data, tab_g, w2_g, batch, out_off);
+}
+// ... with single LDS accesses (real size 32768)
+template <int LOGC, bool FWD, bool SCALE, int LOGE = 4>
+__global__ __launch_bounds__((1 << LOGC) >> LOGE, 4) CLFA_DS_SINGLE_FN void k_rfft_2x_s(cpx *__restrict__ data, const cpx *__restrict__ tab_g,
+                                                                    const cpx *__restrict__ w2_g, long batch, long out_off) {
+  rfft_2x_body<LOGC, FWD, SCALE, LOGE>(data, tab_g, w2_g, batch, out_off);
+}
+
 hipError_t launch_rfft_lds15(bool fwd, cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s,
                              long out_off) {
   if (batch <= 0) return hipSuccess;
@@ -642,8 +666,8 @@ hipError_t launch_rfft_2x13(bool fwd, cpx *data, const FftTables &t, long batch,
   if (batch <= 0) return hipSuccess;
   const long cap = 2L * di.num_cus;   // two 512-lane workgroups per CU
   const int grid = (int)(batch < cap ? batch : cap);
-  if (fwd) hipLaunchKernelGGL((k_rfft_2x<13, true, true>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch, out_off);
-  else hipLaunchKernelGGL((k_rfft_2x<13, false, false>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch, out_off);
+  if (fwd) hipLaunchKernelGGL((k_rfft_2x_s<13, true, true>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch, out_off);
+  else hipLaunchKernelGGL((k_rfft_2x_s<13, false, false>), dim3(grid), dim3(512), 0, s, data, t.half, t.w2, batch, out_off);
   return hipGetLastError();
 }
 
@@ -887,8 +911,7 @@ static hipError_t launch_lds_one(cpx *data, const FftTables &t, long batch, cons
   long cap = (long)di.num_cus * occ;
   int grid = (int)(groups < cap ? groups : cap);
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_fft_lds<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(G::WG), 0, s, data, t.half, t.w2,
-                     batch, out_off);
+  hipLaunchKernelGGL((k_fft_lds<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(G::WG), 0, s, data, t.half, t.w2, batch, out_off);
   return hipGetLastError();
 }
 
@@ -1133,7 +1156,7 @@ __device__ __forceinline__ void four_phase2(const cpx *__restrict__ src, cpx *__
 // The first row block of every slice — rows k1 < KL = NSLICE * R2, 1/8 of the
 // intermediate for n = 65536 — stays in LDS between the phases instead of going through the scratch
 template <int LOGN, bool FWD, bool SCALE>
-__global__ __launch_bounds__(512) void k_fft_4step(cpx *__restrict__ data, cpx *__restrict__ scratch,
+__global__ __launch_bounds__(512) CLFA_DS_SINGLE_FN void k_fft_4step(cpx *__restrict__ data, cpx *__restrict__ scratch,
                                                            const cpx *__restrict__ tabs_g, long batch, long out_off) {
   using G = FourGeom<LOGN>;
   constexpr int NSLICE = 2;        // two 256-lane slices per workgroup
