@@ -941,18 +941,8 @@ int clfa_cfft_transform(clfa_fft *p, float *c, long batch) {
   const size_t per = sizeof(cpx) * (size_t)p->n;
   if (batch > 0 && per * (size_t)batch <= kPinnedZeroCopyMax && one_touch_route(p, batch)) {
     if (void *dv = pinned_dev(p, c, per * (size_t)batch)) {   // an array of clfa_fft_host_alloc: in place over PCIe
-      // measured per call (profiles/host_path_r05.txt): up to 256 KiB the kernels read AND write the caller's memory
-      // (N = 32768: 32.1 us; the copy engine in front costs 5, on both sides 11 more); above it the copy engine brings the
-      // array in and the kernels write the caller's memory (N = 65536: 48.9 us against 52.7 both ways by the kernels, 52.6
-      // both ways by the copy engine, 73.5 for a pageable array through the runtime's own staging)
-      int e;
-      if (per * (size_t)batch <= ((size_t)256 << 10)) {
-        e = clfa_fft_exec_dev(p, dv, batch, p->stream);
-      } else {
-        if ((e = p->stage.ensure(per * batch))) return e;
-        HIP_TRY(hipMemcpyAsync(p->stage.p, c, per * batch, hipMemcpyHostToDevice, p->stream));
-        e = clfa_fft_exec_dev_oop(p, p->stage.p, dv, batch, p->stream);
-      }
+      // (profiles/host_path_r05.txt: N = 65536 42.2 us; with the copy engine bringing the array in first 46.4)
+      const int e = clfa_fft_exec_dev(p, dv, batch, p->stream);
       if (e) return e;
       HIP_TRY(hipStreamSynchronize(p->stream));
       return CLFA_SUCCESS;
