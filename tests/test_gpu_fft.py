@@ -543,6 +543,23 @@ def test_cfft_any_length(n, batch):
     assert_parity(y, x, what="round trip n=%d" % n)
 
 
+def test_cfft_any_length_out_of_place():
+    """the one-launch form (k_blue_lds) from src to dst on device memory: the source is left untouched, ragged groups"""
+    import torch
+    for n, batch in ((1000, 9), (100, 37), (4095, 5)):
+        f = fa.Clcfft(0, n, True)
+        assert f.kernel_name() == "k_blue_lds"
+        src = torch.rand((batch, n, 2), device="cuda") * 2 - 1
+        keep = src.clone()
+        dst = torch.zeros_like(src)
+        assert f.exec_device_oop(src, dst, batch) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(src, keep)
+        x = keep.cpu().numpy().view(np.complex64).reshape(batch, n)
+        y = dst.cpu().numpy().view(np.complex64).reshape(batch, n)
+        assert_parity(y, (np.fft.fft(x.astype(np.complex128), axis=-1) / n).astype(np.complex64), what="oop fwd n=%d" % n)
+
+
 def test_cfft_any_length_chunks():
     """more rows than the 256 MiB convolution workspace holds (m = 2^18 per row of n = 100000): the batch is walked in chunks"""
     import torch
