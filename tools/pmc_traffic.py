@@ -21,7 +21,7 @@ def main(src, tag, key, kernel_substr, root):
         for g in stats:
             if g not in ours and abs(os.path.getmtime(g) - os.path.getmtime(f)) < 300:
                 shutil.copy(g, os.path.join(dst, "reference_opencl_kernel_stats.csv"))
-    for f in ("bench_unprofiled.json", "bench_driver_cmdline.json", "series_steps20.txt", "series_steps100.txt", "series_cold_start.txt", "summary.json"):
+    for f in ("bench_unprofiled.json", "bench_driver_cmdline.json", "series_steps20.txt", "series_steps100.txt", "series_steps1000.txt", "series_steps3000.txt", "series_cold_start.txt", "summary.json"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "summary.json" else "pmc_summary.json"))
     acc = {}
