@@ -871,6 +871,39 @@ __global__ __launch_bounds__(256) void k_fft_small(cpx *__restrict__ data, long 
   }
 }
 
+// How many workgroups of the persistent grids share a CU.  NOT "as many as fit": these kernels keep the next transform's
+// loads in flight behind the current one's passes, so one workgroup per CU already covers the memory latency, and every
+// further one only adds concurrent streams for the memory controllers to interleave.  Chosen per size and packing from
+// interleaved A/Bs on random data, directions alternating (profiles/wgs_per_cu_r05.txt; one / two / three / all that fit):
+// n = 1024 at one workgroup per CU 6.02 TB/s, at the three that fit 5.37; n = 16 .. 2048 and 8192 -4 .. -11 % of the time;
+// n = 8 and n = 4096 like two.  The packed real kernels' pair maps stall between barriers, so they want company: sizes
+// 64 .. 512, 8192 (inverse: three) and 16384 stay at what fits, sizes 8, 16, 2048, 4096 take two, size 1024 one.
+// (CLFA_WGS_TABLE 0: round 4's grids; CLFA_WGS_C / CLFA_WGS_RF + CLFA_WGS_RI: one figure for every size, for A/B builds.)
+// All of this holds for batches that STREAM from HBM: up to about twice the 256 MiB Infinity Cache the same A/B reads the
+// other way (n = 1024: 16 MiB +21 %, 256 MiB +2 %, 512 MiB -5 %, 1 GiB -10 %; n = 64 still +8 % at 768 MiB, -4 % at 1 GiB),
+// so the table applies from 1 GiB of transforms per launch and smaller batches keep every workgroup that fits.
+#ifndef CLFA_WGS_TABLE
+#define CLFA_WGS_TABLE 1
+#endif
+static inline bool streaming_batch(long batch, int logn) { return (batch << logn) >= (1L << 27); }   // 8-byte samples: 1 GiB
+template <int LOGN, int MODE> constexpr int wgs_per_cu() {
+  if (!CLFA_WGS_TABLE) return 64;
+  if (MODE == MODE_C2C) {
+#if defined(CLFA_WGS_C)
+    return CLFA_WGS_C;
+#endif
+    return LOGN == 3 || LOGN == 12 ? 2 : (LOGN >= 4 && LOGN <= 13) ? 1 : 64;
+  }
+#if defined(CLFA_WGS_RF)
+  return MODE == MODE_R2C ? CLFA_WGS_RF : CLFA_WGS_RI;
+#endif
+  switch (LOGN) {   // packed real size 2^(LOGN + 1)
+    case 2: case 3: case 10: case 11: return 2;
+    case 9: return 1;
+    default: return 64;
+  }
+}
+
 template <int LOGN, bool FWD, int MODE, bool SCALE>
 static hipError_t launch_small_one(cpx *data, const FftTables &t, long batch, const DeviceInfo &di, hipStream_t s, long out_off) {
   using G = LdsGeom<LOGN>;
@@ -884,10 +917,76 @@ static hipError_t launch_small_one(cpx *data, const FftTables &t, long batch, co
     }
     occ = nb;
   }
-  long cap = (long)di.num_cus * occ;
+  long cap = (long)di.num_cus * (streaming_batch(batch, LOGN) && wgs_per_cu<LOGN, MODE>() < occ ? wgs_per_cu<LOGN, MODE>() : occ);
   int grid = (int)(groups < cap ? groups : cap);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_fft_small<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(256), 0, s, data, out_off, t.half, t.w2, batch);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// n = 2 and n = 4, complex: a copy kernel with a butterfly in it
+// ---------------------------------------------------------------------------------
+// Every lane moves 16 bytes (two complex samples) per access, lanes in address order — the access shape of a plain copy.
+// n = 2: the lane holds the whole transform.  n = 4: lanes 2k and 2k + 1 hold (x0, x1) and (x2, x3) and read each other's
+// pair through the DPP lane crossbar (quad_perm [1, 0, 3, 2]: four v_mov_dpp, no LDS); the even lane leaves with (X0, X1),
+// the odd one with (X2, X3), so the stores are in address order as well.  The reference's two stages (cl_fft.cpp:24-41 on
+// bit-reversed input): s0 = x0 + x2, d0 = x0 - x2, s1 = x1 + x3, d1 = x1 - x3; X0 = s0 + s1, X2 = s0 - s1,
+// X1 = d0 + w d1, X3 = d0 - w d1, w = -i forward, +i inverse (exact in every rounding).  A workgroup moves contiguous
+// runs of 256 * UNROLL pieces, UNROLL accesses of a lane in flight at once; a ragged tail is clamped on the load side and
+// predicated on the store side (the lanes of a pair are always both inside or both outside: a transform is 32 bytes).
+#ifndef CLFA_TINY
+#define CLFA_TINY 1
+#endif
+__device__ __forceinline__ float dpp_swap1(float v) {   // lane l <- lane l ^ 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+template <int LOGN, bool FWD, bool SCALE, int UNROLL>
+__global__ __launch_bounds__(256) void k_fft_tiny(cpx *__restrict__ data, long out_off, long total16) {
+  static_assert(LOGN == 1 || LOGN == 2, "n = 2 or 4");
+  constexpr float sc = SCALE ? 1.0f / (float)(1 << LOGN) : 1.0f;
+  constexpr long TILE = 256 * UNROLL;   // 16-byte pieces a workgroup moves per iteration: one contiguous run
+  const bool odd = threadIdx.x & 1;
+#pragma unroll 1
+  for (long i0 = (long)blockIdx.x * TILE + threadIdx.x; i0 < total16; i0 += (long)gridDim.x * TILE) {
+    f4v q[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      long i = i0 + u * 256;
+      i = i < total16 ? i : total16 - 1;   // ragged tail: clamped, the result is not stored
+      q[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(data + 2 * i));
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const f4v m = q[u];
+      f4v r;
+      if constexpr (LOGN == 1) {
+        r = f4v{(m.x + m.z) * sc, (m.y + m.w) * sc, (m.x - m.z) * sc, (m.y - m.w) * sc};
+      } else {
+        const f4v o = f4v{dpp_swap1(m.x), dpp_swap1(m.y), dpp_swap1(m.z), dpp_swap1(m.w)};
+        // (x0, x1) = even lane's pair, (x2, x3) = odd lane's: sums are symmetric, differences change sign in the odd lane
+        const float s0x = m.x + o.x, s0y = m.y + o.y, s1x = m.z + o.z, s1y = m.w + o.w;
+        const float d0x = odd ? o.x - m.x : m.x - o.x, d0y = odd ? o.y - m.y : m.y - o.y;
+        const float d1x = odd ? o.z - m.z : m.z - o.z, d1y = odd ? o.w - m.w : m.w - o.w;
+        // w d1, w = -i (forward): (d1y, -d1x); +i (inverse): (-d1y, d1x)
+        const float wx = FWD ? d1y : -d1y, wy = FWD ? -d1x : d1x;
+        r = f4v{(odd ? s0x - s1x : s0x + s1x) * sc, (odd ? s0y - s1y : s0y + s1y) * sc,
+                (odd ? d0x - wx : d0x + wx) * sc, (odd ? d0y - wy : d0y + wy) * sc};
+      }
+      const long i = i0 + u * 256;
+      if (i < total16) st_nt16(data + out_off + 2 * i, r);
+    }
+  }
+}
+// Two accesses per lane in flight and four workgroups per CU: 5.9-6.1 TB/s in place (the chip's plain copy); one or eight
+// workgroups per CU, or four / eight accesses per lane, 3.3-5.8 (profiles/tiny_r05.txt).
+template <int LOGN, bool FWD, bool SCALE>
+static hipError_t launch_tiny_one(cpx *data, long batch, const DeviceInfo &di, hipStream_t s, long out_off) {
+  constexpr int UNROLL = 2;
+  const long total16 = batch << (LOGN - 1);   // 16-byte pieces
+  const long want = (total16 + 256 * UNROLL - 1) / (256 * UNROLL);
+  const long cap = 4L * di.num_cus;
+  hipLaunchKernelGGL((k_fft_tiny<LOGN, FWD, SCALE, UNROLL>), dim3((int)(want < cap ? want : cap)), dim3(256), 0, s, data, out_off, total16);
   return hipGetLastError();
 }
 
@@ -908,7 +1007,7 @@ static hipError_t launch_lds_one(cpx *data, const FftTables &t, long batch, cons
     }
     occ = nb;
   }
-  long cap = (long)di.num_cus * occ;
+  long cap = (long)di.num_cus * (streaming_batch(batch, LOGN) && wgs_per_cu<LOGN, MODE>() < occ ? wgs_per_cu<LOGN, MODE>() : occ);
   int grid = (int)(groups < cap ? groups : cap);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_fft_lds<LOGN, FWD, MODE, SCALE>), dim3(grid), dim3(G::WG), 0, s, data, t.half, t.w2, batch, out_off);
@@ -920,6 +1019,7 @@ static hipError_t launch_lds_n(bool fwd, int mode, bool scale, cpx *data, const 
                                const DeviceInfo &di, hipStream_t s, long out_off) {
 #define CLFA_CASE(F, M, S)                                                                                     \
   if (fwd == F && mode == M && scale == S) {                                                                   \
+    if constexpr (CLFA_TINY && LOGN <= 2 && M == MODE_C2C) return launch_tiny_one<LOGN, F, S>(data, batch, di, s, out_off); \
     /* sub-64-byte rows per transform (and the packed real transforms up to 256 bins, whose pair maps  */     \
     /* store 8-byte pieces): coalesced staging through LDS                                              */     \
     if constexpr (LOGN >= 2 && (LOGN <= 6 || (M != MODE_C2C && LOGN <= 8)))                                     \
@@ -951,6 +1051,7 @@ hipError_t launch_fft_lds(int logn, bool fwd, int mode, bool scale, cpx *data, c
 }
 
 const char *name_fft_lds(int logn, bool, int mode) {
+  if (CLFA_TINY && logn <= 2 && mode == MODE_C2C) return "k_fft_tiny";
   if (logn >= 2 && (logn <= 6 || (mode != MODE_C2C && logn <= 8))) return "k_fft_small";
   return "k_fft_lds";
 }

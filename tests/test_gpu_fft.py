@@ -94,6 +94,35 @@ def test_cfft_batched_ragged(n, batch):
         assert_parity(y, oracle.cfft(x, fwd), what="n=%d batch=%d" % (n, batch))
 
 
+@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("batch", [1, 2, 3, 127, 255, 257, 1025, 100003, 2099201])
+def test_cfft_tiny_kernel_ragged(n, batch):
+    """k_fft_tiny (n = 2 in one lane, n = 4 in a lane pair through DPP): batch counts around every boundary of its tiling
+    (a lane pair, a 512-piece run of a workgroup, the grid), in place with a guard behind the batch, out of place with the
+    source untouched"""
+    import torch
+    x = util.lcg_complex(31 * n + batch, n * batch).reshape(batch, n)
+    for fwd in (True, False):
+        plan = fa.Clcfft(0, n, fwd)
+        assert plan.kernel_name() == "k_fft_tiny"
+        buf = torch.full((batch + 64, n, 2), 7.0, device="cuda")
+        buf[:batch] = torch.from_numpy(x.view(np.float32).reshape(batch, n, 2))
+        src = buf[:batch].clone()
+        assert plan.exec_device(buf, batch) == 0
+        torch.cuda.synchronize()
+        assert bool(torch.all(buf[batch:] == 7.0)), "wrote behind the batch"
+        got = buf[:batch].cpu().numpy().view(np.complex64).reshape(batch, n)
+        pick = np.unique(np.concatenate([np.arange(min(batch, 600)), np.arange(max(0, batch - 600), batch), np.arange(0, batch, 4099)]))
+        want = oracle.cfft(x[pick], fwd)
+        assert_parity(got[pick], want, what="n=%d fwd=%s batch=%d" % (n, fwd, batch))
+        keep = src.clone()
+        dst = torch.full_like(src, float("nan"))
+        assert plan.exec_device_oop(src, dst, batch) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(src.view(torch.int32), keep.view(torch.int32)), "source modified"
+        assert torch.equal(dst.view(torch.int32), buf[:batch].view(torch.int32)), "out of place differs from in place"
+
+
 def test_cfft_empty_batch_and_bad_sizes():
     plan = fa.Clcfft(0, 64, True)
     assert plan.transform(np.zeros((0, 64), np.complex64)) == 0
@@ -487,6 +516,33 @@ def test_config3_full_size_roundtrip():
     torch.cuda.synchronize()
     err = float((d - orig).double().norm() / orig.double().norm())
     assert err < TOL
+
+
+@pytest.mark.parametrize("real,n", [(False, 16), (False, 1024), (False, 8192), (True, 8), (True, 1024), (True, 4096)])
+def test_streaming_batches_on_the_reduced_grid(real, n):
+    """1 GiB of transforms per launch and one more (ragged): from there the persistent grids of k_fft_small / k_fft_lds put
+    one or two workgroups on a CU instead of all that fit (wgs_per_cu(), fft_kernels.hip) — same transforms, longer
+    grid-stride loops: picked transforms against the oracle, all of them through the round trip"""
+    import torch
+    per = n * (4 if real else 8)
+    batch = (1 << 30) // per + 1
+    g = torch.Generator(device="cuda").manual_seed(n)
+    d = torch.rand((batch, n) if real else (batch, n, 2), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    orig = d.clone()
+    pick = [0, 1, batch // 3, batch - 2, batch - 1]
+    keep = {b: d[b].cpu().numpy() for b in pick}
+    f, i = (fa.Clrfft(0, n, True), fa.Clrfft(0, n, False)) if real else (fa.Clcfft(0, n, True), fa.Clcfft(0, n, False))
+    assert f.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    for b, x in keep.items():
+        got = d[b].cpu().numpy().reshape(-1).view(np.complex64)
+        want = oracle.rfft_forward(x) if real else oracle.cfft(x.reshape(-1).view(np.complex64), True)
+        assert_parity(got, want, what="%s n=%d transform %d of %d" % ("real" if real else "complex", n, b, batch))
+    assert i.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    err = float((d - orig).double().norm() / orig.double().norm())
+    worst = float((d - orig).abs().max())
+    assert err < TOL and worst < 1e-5, (err, worst)
 
 
 # ---- beyond the reference: n = 2^17 .. 2^24 (SURVEY.md section 8f, row 4) ---------------------------
