@@ -80,7 +80,7 @@ CLFA_API int clfa_r2c_twiddle_table(int m, int forward, float *out);
 /* ---- complex FFT: cl_fft::Clcfft ------------------------------------------- */
 /* Clcfft::Clcfft(device_id, size, fwd), cl_fft.cpp:44-125.  n = 2^k, 2..65536 is the reference's
  * range (its stage kernel overflows int32 above that, cl_fft.cpp:32); as an extension n up to 2^24
- * is accepted (two passes up to 2^20, three above; 256 MiB of workspace), and so is any length 2..2^22
+ * is accepted (two passes up to 2^22, three above; 256 MiB of workspace), and so is any length 2..2^22
  * that is not a power of two (the reference's callers pad those, opcode.cpp:30-35): exact DFT by Bluestein's
  * algorithm around two power-of-two plans, same scaling conventions.
  * On failure *plan is still a valid handle whose clfa_fft_get_error() reports

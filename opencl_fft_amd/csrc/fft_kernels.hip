@@ -1494,7 +1494,7 @@ const char *name_fft_4step(int logn) { return logn == 16 ? "k_fft_res16" : "k_ff
 // n = 2^17 .. 2^24: beyond the reference's reach (its stage kernel overflows int32 above 65536,
 // cl_fft.cpp:32) — an extension, composed from the kernels above
 // ---------------------------------------------------------------------------------
-// Above 2^20 (two passes below it, see k_big2_*): n = N1 x N2, N1 = 32..256 (columns), N2 = 8192..65536 (rows):
+// Above 2^22 (two passes up to there, see k_big2_*): n = N1 x N2, N1 = 128, 256 (columns), N2 = 65536 (rows):
 //   1. k_big_cols: N1-point FFT down 16..128 adjacent columns of data[n1][n2], times W_n^(n2 k1),
 //      to scratch[k1][n2]                                                       (16 B/sample)
 //   2. the batched row kernel of this file over the n-contiguous rows of scratch, N1 * batch of them,
@@ -1504,11 +1504,19 @@ const char *name_fft_4step(int logn) { return logn == 16 ? "k_fft_res16" : "k_ff
 // Twiddles W_n^e = lo[e mod 4096] * hi[e / 4096], both tables rounded from double, read from global
 // memory (64 KiB in all: cache-resident).
 
+#ifndef CLFA_BIG2_MAX
+#define CLFA_BIG2_MAX 22   // the largest two-pass size (20: round 4's three passes for 2^21 and 2^22, for A/B builds)
+#endif
+constexpr int kBig2MaxLog = CLFA_BIG2_MAX;
+#ifndef CLFA_BIG2_ODD_UP
+#define CLFA_BIG2_ODD_UP 1   // n = 2^21: the 2048-point factor in the rows (0) or in the columns (1: 2.04 -> 2.30 TB/s)
+#endif
+
 int big_split(int logn, BigGeom *g) {
   if (logn <= kMaxLog || logn > kBigMaxLog) return -1;
   g->logn = logn;
-  if (logn <= 20) {   // two passes, N1 x N2 with both <= 1024 (k_big2_cols / k_big2_rows)
-    g->logn1 = logn / 2;
+  if (logn <= kBig2MaxLog) {   // two passes, N1 x N2 with both <= 2048 (k_big2_cols / k_big2_rows)
+    g->logn1 = (logn + (logn == 21 ? CLFA_BIG2_ODD_UP : 0)) / 2;
     g->logn2 = logn - g->logn1;
   } else {            // three passes
     g->logn2 = logn == 21 ? 13 : logn - 8;
@@ -1596,7 +1604,7 @@ static hipError_t launch_big_n1(const BigGeom &g, bool fwd, bool scale, cpx *dat
   return hipGetLastError();
 }
 
-// ---- n = 2^17 .. 2^20 in TWO passes (32 B/sample): both factors <= 1024, so a block of 16 columns
+// ---- n = 2^17 .. 2^22 in TWO passes (32 B/sample): both factors <= 2048, so a block of 16 columns
 // (pass 1) or 16 rows (pass 2) of one transform fits the LDS of a CU (128-139 KiB, one workgroup of
 // N1 resp. N2 lanes per CU) and both passes move 128-byte segments:
 //   k_big2_cols: data[n1][16 columns] -> N1-point FFTs, times W_n^(n2 k1) -> scratch[k1][n2]
@@ -1642,12 +1650,16 @@ __global__ __launch_bounds__(1 << LOGN1) void k_big2_cols(const cpx *__restrict_
 // N1 = 1024 in the two-run form of k_cfft_2x: the block's 16 columns x 1024 rows as two
 // 512-point runs per column (even / odd rows) through ONE 64 KiB exchange buffer and a radix-2 step in registers —
 // 512 lanes and half the LDS, so two workgroups share a CU where the one-run form (128 KiB) leaves one
-template <bool FWD>
-__global__ __launch_bounds__(512, 4) void k_big2_cols_2x(const cpx *__restrict__ data, cpx *__restrict__ scratch,
+// (LOGC = 10, round 5: N1 = 2048 as two 1024-point runs, 1024 lanes and 140 KiB of LDS, one workgroup per CU — what puts
+// n = 2^21 and 2^22 on two passes of 128-byte segments: 1.70 -> 2.30 / 2.12 TB/s algorithmic.  Blocks of 8 columns, the other
+// way to fit 2048 rows into LDS, copy at 3.8-4.1 TB/s against 5.3 for 16; a persistent form of both kernels that loads the
+// next block under the stores of this one measured slower (profiles/big_two_pass_r05.txt).)
+template <int LOGC, bool FWD>
+__global__ __launch_bounds__(1 << LOGC, LOGC == 9 ? 4 : 1) void k_big2_cols_2x(const cpx *__restrict__ data, cpx *__restrict__ scratch,
                                                          const cpx *__restrict__ tabs_g, int logn2, int loglo) {
-  constexpr int LOGC = 9, M = 1 << LOGC, TC = M / 16;   // 512-point runs, 32 lanes per column
-  __shared__ cpx s_tabh[M / 2];   // W_512^k
-  __shared__ cpx s_tabj[M];       // W_1024^k, k < 512 (the radix-2 step)
+  constexpr int M = 1 << LOGC, TC = M / 16;   // M-point runs, TC lanes per column
+  __shared__ cpx s_tabh[M / 2];   // W_M^k
+  __shared__ cpx s_tabj[M];       // W_2M^k, k < M (the radix-2 step)
   __shared__ cpx s_x[M * 16];
   const int tid = threadIdx.x;
   s_tabj[tid] = tabs_g[tid];
@@ -1672,7 +1684,7 @@ __global__ __launch_bounds__(512, 4) void k_big2_cols_2x(const cpx *__restrict__
     const int k = tf + TC * e;
     const cpx p = cmulc<!FWD>(vb[e], s_tabj[k]);
     const cpx o0 = cadd(va[e], p), o1 = csub(va[e], p);
-    const int ex0 = n2 * k, ex1 = n2 * (k + M);  // < n <= 2^20
+    const int ex0 = n2 * k, ex1 = n2 * (k + M);  // < n <= 2^22
     scratch[base + ((long)k << logn2)] = cmulc<!FWD>(o0, cmul(tlo[ex0 & mlo], thi[ex0 >> loglo]));
     scratch[base + ((long)(k + M) << logn2)] = cmulc<!FWD>(o1, cmul(tlo[ex1 & mlo], thi[ex1 >> loglo]));
   }
@@ -1728,12 +1740,12 @@ __global__ __launch_bounds__(1 << LOGN2) void k_big2_rows(const cpx *__restrict_
 
 // N2 = 1024 in the two-run form: 16 rows x 1024 points as two 512-point runs per row (one 16-byte load per lane brings
 // an even and an odd sample), the last pass with the rows on the fast lane index as above, radix-2 step in registers
-template <bool FWD, bool SCALE>
-__global__ __launch_bounds__(512, 4) void k_big2_rows_2x(const cpx *__restrict__ scratch, cpx *__restrict__ data,
+template <int LOGC, bool FWD, bool SCALE>
+__global__ __launch_bounds__(1 << LOGC, LOGC == 9 ? 4 : 1) void k_big2_rows_2x(const cpx *__restrict__ scratch, cpx *__restrict__ data,
                                                          const cpx *__restrict__ tab_g, int logn1, float inv_n) {
-  constexpr int LOGC = 9, M = 1 << LOGC, TC = M / 16, S2 = lds_padded_size(M) | 1;
-  __shared__ cpx s_tabh[M / 2];   // W_512^k
-  __shared__ cpx s_tabj[M];       // W_1024^k, k < 512
+  constexpr int M = 1 << LOGC, TC = M / 16, S2 = lds_padded_size(M) | 1;
+  __shared__ cpx s_tabh[M / 2];   // W_M^k
+  __shared__ cpx s_tabj[M];       // W_2M^k, k < M
   __shared__ cpx s_x[16 * S2];
   const int l = threadIdx.x;
   s_tabj[l] = tab_g[l];
@@ -1788,32 +1800,37 @@ static hipError_t launch_big2_rows(const BigGeom &g, bool fwd, bool scale, const
   else hipLaunchKernelGGL((k_big2_rows<LOGN2, false, false>), grid, dim3(1 << LOGN2), 0, s, scratch, data, half2, g.logn1, inv_n);
   return hipGetLastError();
 }
+template <int LOGC>
+static hipError_t launch_big2_cols_2x(const BigGeom &g, bool fwd, const cpx *data, cpx *scratch, const cpx *bigtabs, long batch, hipStream_t s) {
+  const dim3 grid((1 << g.logn2) / 16, (unsigned)batch);
+  if (fwd) hipLaunchKernelGGL((k_big2_cols_2x<LOGC, true>), grid, dim3(1 << LOGC), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  else hipLaunchKernelGGL((k_big2_cols_2x<LOGC, false>), grid, dim3(1 << LOGC), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  return hipGetLastError();
+}
+template <int LOGC>
+static hipError_t launch_big2_rows_2x(const BigGeom &g, bool fwd, bool scale, const cpx *scratch, cpx *out, const cpx *half2, long batch, hipStream_t s) {
+  const dim3 grid((1 << g.logn1) / 16, (unsigned)batch);
+  const float inv_n = 1.0f / (float)(1L << g.logn);
+  if (fwd && scale) hipLaunchKernelGGL((k_big2_rows_2x<LOGC, true, true>), grid, dim3(1 << LOGC), 0, s, scratch, out, half2, g.logn1, inv_n);
+  else if (fwd) hipLaunchKernelGGL((k_big2_rows_2x<LOGC, true, false>), grid, dim3(1 << LOGC), 0, s, scratch, out, half2, g.logn1, inv_n);
+  else hipLaunchKernelGGL((k_big2_rows_2x<LOGC, false, false>), grid, dim3(1 << LOGC), 0, s, scratch, out, half2, g.logn1, inv_n);
+  return hipGetLastError();
+}
 static hipError_t launch_fft_big2(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *out, cpx *scratch, const cpx *bigtabs,
                                   const FftTables &sub, long batch, hipStream_t s) {
   hipError_t e;
   switch (g.logn1) {
     case 8: e = launch_big2_cols<8>(g, fwd, data, scratch, bigtabs, batch, s); break;
     case 9: e = launch_big2_cols<9>(g, fwd, data, scratch, bigtabs, batch, s); break;
-    case 10: {   // 1024-point columns as two 512-point runs (two workgroups per CU)
-      const dim3 grid((1 << g.logn2) / 16, (unsigned)batch);
-      if (fwd) hipLaunchKernelGGL((k_big2_cols_2x<true>), grid, dim3(512), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
-      else hipLaunchKernelGGL((k_big2_cols_2x<false>), grid, dim3(512), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
-      e = hipGetLastError();
-      break;
-    }
+    case 10: e = launch_big2_cols_2x<9>(g, fwd, data, scratch, bigtabs, batch, s); break;    // 1024-point columns as two 512-point runs (two workgroups per CU)
+    case 11: e = launch_big2_cols_2x<10>(g, fwd, data, scratch, bigtabs, batch, s); break;   // 2048-point columns as two 1024-point runs
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
   switch (g.logn2) {
     case 9: return launch_big2_rows<9>(g, fwd, scale, scratch, out, sub.half, batch, s);
-    case 10: {   // ... and the 1024-point rows
-      const dim3 grid((1 << g.logn1) / 16, (unsigned)batch);
-      const float inv_n = 1.0f / (float)(1L << g.logn);
-      if (fwd && scale) hipLaunchKernelGGL((k_big2_rows_2x<true, true>), grid, dim3(512), 0, s, scratch, out, sub.half, g.logn1, inv_n);
-      else if (fwd) hipLaunchKernelGGL((k_big2_rows_2x<true, false>), grid, dim3(512), 0, s, scratch, out, sub.half, g.logn1, inv_n);
-      else hipLaunchKernelGGL((k_big2_rows_2x<false, false>), grid, dim3(512), 0, s, scratch, out, sub.half, g.logn1, inv_n);
-      return hipGetLastError();
-    }
+    case 10: return launch_big2_rows_2x<9>(g, fwd, scale, scratch, out, sub.half, batch, s);
+    case 11: return launch_big2_rows_2x<10>(g, fwd, scale, scratch, out, sub.half, batch, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1823,7 +1840,7 @@ hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx
                           const cpx *bigtabs, const FftTables &sub, long batch, const DeviceInfo &di, hipStream_t s) {
   if (batch <= 0) return hipSuccess;
   if (batch > 65535) return hipErrorInvalidValue;
-  if (g.logn <= 20) return launch_fft_big2(g, fwd, scale, data, out, scratch, bigtabs, sub, batch, s);
+  if (g.logn <= kBig2MaxLog) return launch_fft_big2(g, fwd, scale, data, out, scratch, bigtabs, sub, batch, s);
   switch (g.logn1) {
     case 5: return launch_big_n1<5>(g, fwd, scale, data, out, scratch, scratch2, bigtabs, sub, batch, di, s);
     case 6: return launch_big_n1<6>(g, fwd, scale, data, out, scratch, scratch2, bigtabs, sub, batch, di, s);
