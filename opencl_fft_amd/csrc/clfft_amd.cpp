@@ -512,14 +512,16 @@ static int fft_setup(clfa_fft *p, int device, int n, bool real, int size, bool f
     big_split(p->logn, &p->big);
     rowlog = p->big.logn2;
     rown = 1 << rowlog;
-    const int n1 = 1 << p->big.logn1, lo = 1 << p->big.loglo;
+    const int n1 = 1 << p->big.logn1;
     std::vector<cpx> all, part;
     fill_twiddle(part, n1 / 2, n1, 1, -1.f);
     all.insert(all.end(), part.begin(), part.begin() + n1 / 2);
-    fill_twiddle(part, lo, n, 1, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + lo);
-    fill_twiddle(part, n / lo, n, lo, -1.f);
-    all.insert(all.end(), part.begin(), part.begin() + n / lo);
+    fill_twiddle(part, 128, n, 1, -1.f);              // W_n^e, e = e0 + 128 e1 + 16384 e2 (big_tw(), fft_kernels.hip)
+    all.insert(all.end(), part.begin(), part.begin() + 128);
+    fill_twiddle(part, 128, n, 128, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + 128);
+    fill_twiddle(part, n / 16384, n, 16384, -1.f);
+    all.insert(all.end(), part.begin(), part.begin() + n / 16384);
     if ((e = upload(p->bigtabs, all.data(), sizeof(cpx) * all.size()))) return e;
     // workspace: as many whole transforms as fit 256 MiB (at least one); exec walks the batch in such chunks
     size_t per = sizeof(cpx) * (size_t)n, cap = (size_t)256 << 20;

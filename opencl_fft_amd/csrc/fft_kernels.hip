@@ -1501,8 +1501,7 @@ const char *name_fft_4step(int logn) { return logn == 16 ? "k_fft_res16" : "k_ff
 //      in place: k_fft_lds (N2 <= 8192, 16 B/sample) or the four-step kernel (32 B/sample)
 //   3. k_big_transpose: scratch[k1][k2] -> data[k2 * N1 + k1] (natural order), times 1/n for forward
 //      plans                                                                     (16 B/sample)
-// Twiddles W_n^e = lo[e mod 4096] * hi[e / 4096], both tables rounded from double, read from global
-// memory (64 KiB in all: cache-resident).
+// Twiddles W_n^e: big_tw() below.
 
 #ifndef CLFA_BIG2_MAX
 #define CLFA_BIG2_MAX 22   // the largest two-pass size (20: round 4's three passes for 2^21 and 2^22, for A/B builds)
@@ -1522,7 +1521,6 @@ int big_split(int logn, BigGeom *g) {
     g->logn2 = logn == 21 ? 13 : logn - 8;
     g->logn1 = logn - g->logn2;
   }
-  g->loglo = 12;
   g->two_run = true;   // (the one-run form of the 1024-point blocks lost its A/B by 1.4-6 % and left the library in round 4)
   return 0;
 }
@@ -1531,15 +1529,29 @@ int big_split(int logn, BigGeom *g) {
 #define CLFA_BIG_XCD 1   // the column / row block a workgroup of the two-pass kernels takes: XCD-compact (xcd_first) or blockIdx.x
 #endif
 #define CLFA_BIGX ((int)(CLFA_BIG_XCD ? xcd_first(blockIdx.x, gridDim.x) : blockIdx.x))
+// W_n^e between the passes: e = e0 + 128 e1 + 16384 e2 from three tables of 128, 128 and n / 16384 entries (each rounded from
+// double) in LDS, two multiplies: rms error of the factor 3.9e-8 where the two-table form it replaces had 3.4e-8 (a first table
+// of W_n^e0 - 1, applied as a + a d, is no better: 4.0e-8), against 2.5-4e-7 of a whole transform.
+// (Rounds 2-4 read two tables of 4096 and n / 4096 entries from global memory, one multiply: 64 more vector-memory instructions
+// per lane and block than the 64 that move the data — without them the column passes run 12-34 % faster,
+// profiles/big_two_pass_r05.txt.)
+constexpr int kBigTwFixed = 256;   // entries of the first two tables
+__device__ __forceinline__ void big_tw_fill(cpx *s_tw, const cpx *tw_g, int ntw, int tid, int lanes) {
+  for (int i = tid; i < ntw; i += lanes) s_tw[i] = tw_g[i];
+}
+__device__ __forceinline__ cpx big_tw(const cpx *s_tw, int ex) {
+  return cmul(cmul(s_tw[ex & 127], s_tw[128 + ((ex >> 7) & 127)]), s_tw[kBigTwFixed + (ex >> 14)]);
+}
 template <int LOGN1, bool FWD>
 __global__ __launch_bounds__(256) void k_big_cols(const cpx *__restrict__ data, cpx *__restrict__ scratch,
-                                                  const cpx *__restrict__ tabs_g, int logn2, int loglo) {
+                                                  const cpx *__restrict__ tabs_g, int logn2, int ntw) {
   constexpr int N1 = 1 << LOGN1, T1 = N1 / 16, C1 = 256 / T1;
   __shared__ cpx s_tab1[N1 / 2];
+  __shared__ cpx s_tw[kBigTwFixed + (1 << (kBigMaxLog - 14))];
   __shared__ cpx s_x[N1 * C1];
   const int tid = threadIdx.x;
   for (int i = tid; i < N1 / 2; i += 256) s_tab1[i] = tabs_g[i];
-  const cpx *tlo = tabs_g + N1 / 2, *thi = tlo + (1 << loglo);
+  big_tw_fill(s_tw, tabs_g + N1 / 2, ntw, tid, 256);
   const int col = tid % C1, tf = tid / C1;
   const int n2 = CLFA_BIGX * C1 + col;
   const long base = ((long)blockIdx.y << (LOGN1 + logn2)) + n2;
@@ -1552,12 +1564,11 @@ __global__ __launch_bounds__(256) void k_big_cols(const cpx *__restrict__ data, 
   __syncthreads();
   pass_gather<LOGN1, 4>(v, tf, [&](int p) { return s_x[p * C1 + col]; });
   pass_compute<LOGN1, 4, 4, FWD>(v, tf, s_tab1);
-  const int mlo = (1 << loglo) - 1;
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const int k1 = tf + T1 * e;
     const int ex = n2 * k1;  // < n <= 2^24
-    scratch[base + ((long)k1 << logn2)] = cmulc<!FWD>(v[e], cmul(tlo[ex & mlo], thi[ex >> loglo]));
+    scratch[base + ((long)k1 << logn2)] = cmulc<!FWD>(v[e], big_tw(s_tw, ex));
   }
 }
 
@@ -1591,8 +1602,8 @@ static hipError_t launch_big_n1(const BigGeom &g, bool fwd, bool scale, cpx *dat
   constexpr int N1 = 1 << LOGN1, T1 = N1 / 16, C1 = 256 / T1, TK1 = N1 < 64 ? N1 : 64, TK2 = 4096 / TK1;
   const int n2 = 1 << g.logn2;
   const dim3 gc(n2 / C1, (unsigned)batch), gt(n2 / TK2, N1 / TK1, (unsigned)batch);
-  if (fwd) hipLaunchKernelGGL((k_big_cols<LOGN1, true>), gc, dim3(256), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
-  else hipLaunchKernelGGL((k_big_cols<LOGN1, false>), gc, dim3(256), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  if (fwd) hipLaunchKernelGGL((k_big_cols<LOGN1, true>), gc, dim3(256), 0, s, data, scratch, bigtabs, g.logn2, kBigTwFixed + (1 << (g.logn > 14 ? g.logn - 14 : 0)));
+  else hipLaunchKernelGGL((k_big_cols<LOGN1, false>), gc, dim3(256), 0, s, data, scratch, bigtabs, g.logn2, kBigTwFixed + (1 << (g.logn > 14 ? g.logn - 14 : 0)));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (g.logn2 <= kLdsMaxLog) e = launch_fft_lds(g.logn2, fwd, MODE_C2C, false, scratch, sub, batch * N1, di, s, 0);
@@ -1623,13 +1634,14 @@ __device__ __forceinline__ void col_passes(cpx (&v)[16], int tf, const cpx *tab,
 }
 template <int LOGN1, bool FWD>
 __global__ __launch_bounds__(1 << LOGN1) void k_big2_cols(const cpx *__restrict__ data, cpx *__restrict__ scratch,
-                                                          const cpx *__restrict__ tabs_g, int logn2, int loglo) {
+                                                          const cpx *__restrict__ tabs_g, int logn2, int ntw) {
   constexpr int N1 = 1 << LOGN1, T1 = N1 / 16;
   __shared__ cpx s_tab1[N1 / 2];
+  __shared__ cpx s_tw[kBigTwFixed + (1 << (2 * LOGN1 + 1 - 14))];   // n <= 2^(2 LOGN1 + 1)
   __shared__ cpx s_x[N1 * 16];
   const int tid = threadIdx.x;
   for (int i = tid; i < N1 / 2; i += N1) s_tab1[i] = tabs_g[i];
-  const cpx *tlo = tabs_g + N1 / 2, *thi = tlo + (1 << loglo);
+  big_tw_fill(s_tw, tabs_g + N1 / 2, ntw, tid, N1);
   const int col = tid % 16, tf = tid / 16;
   const int n2 = CLFA_BIGX * 16 + col;
   const long base = ((long)blockIdx.y << (LOGN1 + logn2)) + n2;
@@ -1638,12 +1650,11 @@ __global__ __launch_bounds__(1 << LOGN1) void k_big2_cols(const cpx *__restrict_
   for (int e = 0; e < 16; e++) v[e] = ld_nt(data + base + ((long)(tf + T1 * e) << logn2));
   __syncthreads();
   col_passes<LOGN1, 0, FWD>(v, tf, s_tab1, s_x, col);
-  const int mlo = (1 << loglo) - 1;
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const int k1 = tf + T1 * e;
-    const int ex = n2 * k1;  // < n <= 2^20
-    scratch[base + ((long)k1 << logn2)] = cmulc<!FWD>(v[e], cmul(tlo[ex & mlo], thi[ex >> loglo]));
+    const int ex = n2 * k1;  // < n <= 2^19
+    scratch[base + ((long)k1 << logn2)] = cmulc<!FWD>(v[e], big_tw(s_tw, ex));
   }
 }
 
@@ -1656,15 +1667,16 @@ __global__ __launch_bounds__(1 << LOGN1) void k_big2_cols(const cpx *__restrict_
 // next block under the stores of this one measured slower (profiles/big_two_pass_r05.txt).)
 template <int LOGC, bool FWD>
 __global__ __launch_bounds__(1 << LOGC, LOGC == 9 ? 4 : 1) void k_big2_cols_2x(const cpx *__restrict__ data, cpx *__restrict__ scratch,
-                                                         const cpx *__restrict__ tabs_g, int logn2, int loglo) {
+                                                         const cpx *__restrict__ tabs_g, int logn2, int ntw) {
   constexpr int M = 1 << LOGC, TC = M / 16;   // M-point runs, TC lanes per column
   __shared__ cpx s_tabh[M / 2];   // W_M^k
   __shared__ cpx s_tabj[M];       // W_2M^k, k < M (the radix-2 step)
+  __shared__ cpx s_tw[kBigTwFixed + (1 << (2 * (LOGC + 1) - 14))];   // n <= 2^(2 (LOGC + 1))
   __shared__ cpx s_x[M * 16];
   const int tid = threadIdx.x;
   s_tabj[tid] = tabs_g[tid];
   if (tid < M / 2) s_tabh[tid] = tabs_g[2 * tid];
-  const cpx *tlo = tabs_g + M, *thi = tlo + (1 << loglo);
+  big_tw_fill(s_tw, tabs_g + M, ntw, tid, M);
   const int col = tid % 16, tf = tid / 16;
   const int n2 = CLFA_BIGX * 16 + col;
   const long base = ((long)blockIdx.y << (LOGC + 1 + logn2)) + n2;
@@ -1678,15 +1690,14 @@ __global__ __launch_bounds__(1 << LOGC, LOGC == 9 ? 4 : 1) void k_big2_cols_2x(c
   col_passes<LOGC, 0, FWD>(va, tf, s_tabh, s_x, col);
   __syncthreads();
   col_passes<LOGC, 0, FWD>(vb, tf, s_tabh, s_x, col);
-  const int mlo = (1 << loglo) - 1;
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const int k = tf + TC * e;
     const cpx p = cmulc<!FWD>(vb[e], s_tabj[k]);
     const cpx o0 = cadd(va[e], p), o1 = csub(va[e], p);
     const int ex0 = n2 * k, ex1 = n2 * (k + M);  // < n <= 2^22
-    scratch[base + ((long)k << logn2)] = cmulc<!FWD>(o0, cmul(tlo[ex0 & mlo], thi[ex0 >> loglo]));
-    scratch[base + ((long)(k + M) << logn2)] = cmulc<!FWD>(o1, cmul(tlo[ex1 & mlo], thi[ex1 >> loglo]));
+    scratch[base + ((long)k << logn2)] = cmulc<!FWD>(o0, big_tw(s_tw, ex0));
+    scratch[base + ((long)(k + M) << logn2)] = cmulc<!FWD>(o1, big_tw(s_tw, ex1));
   }
 }
 
@@ -1786,8 +1797,8 @@ template <int LOGN1>
 static hipError_t launch_big2_cols(const BigGeom &g, bool fwd, const cpx *data, cpx *scratch, const cpx *bigtabs,
                                    long batch, hipStream_t s) {
   const dim3 grid((1 << g.logn2) / 16, (unsigned)batch);
-  if (fwd) hipLaunchKernelGGL((k_big2_cols<LOGN1, true>), grid, dim3(1 << LOGN1), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
-  else hipLaunchKernelGGL((k_big2_cols<LOGN1, false>), grid, dim3(1 << LOGN1), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  if (fwd) hipLaunchKernelGGL((k_big2_cols<LOGN1, true>), grid, dim3(1 << LOGN1), 0, s, data, scratch, bigtabs, g.logn2, kBigTwFixed + (1 << (g.logn > 14 ? g.logn - 14 : 0)));
+  else hipLaunchKernelGGL((k_big2_cols<LOGN1, false>), grid, dim3(1 << LOGN1), 0, s, data, scratch, bigtabs, g.logn2, kBigTwFixed + (1 << (g.logn > 14 ? g.logn - 14 : 0)));
   return hipGetLastError();
 }
 template <int LOGN2>
@@ -1803,8 +1814,8 @@ static hipError_t launch_big2_rows(const BigGeom &g, bool fwd, bool scale, const
 template <int LOGC>
 static hipError_t launch_big2_cols_2x(const BigGeom &g, bool fwd, const cpx *data, cpx *scratch, const cpx *bigtabs, long batch, hipStream_t s) {
   const dim3 grid((1 << g.logn2) / 16, (unsigned)batch);
-  if (fwd) hipLaunchKernelGGL((k_big2_cols_2x<LOGC, true>), grid, dim3(1 << LOGC), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
-  else hipLaunchKernelGGL((k_big2_cols_2x<LOGC, false>), grid, dim3(1 << LOGC), 0, s, data, scratch, bigtabs, g.logn2, g.loglo);
+  if (fwd) hipLaunchKernelGGL((k_big2_cols_2x<LOGC, true>), grid, dim3(1 << LOGC), 0, s, data, scratch, bigtabs, g.logn2, kBigTwFixed + (1 << (g.logn > 14 ? g.logn - 14 : 0)));
+  else hipLaunchKernelGGL((k_big2_cols_2x<LOGC, false>), grid, dim3(1 << LOGC), 0, s, data, scratch, bigtabs, g.logn2, kBigTwFixed + (1 << (g.logn > 14 ? g.logn - 14 : 0)));
   return hipGetLastError();
 }
 template <int LOGC>

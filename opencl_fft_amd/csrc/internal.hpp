@@ -90,11 +90,11 @@ hipError_t launch_crfft_res16(const cpx *data, cpx *out, cpx *slots, const cpx *
 // n = 2^17 .. 2^kBigMaxLog (extension: the reference overflows above 65536): columns + rows + transpose
 constexpr int kBigMaxLog = 24;
 struct BigGeom {
-  int logn, logn1, logn2, loglo;   // n = 2^logn1 x 2^logn2; twiddle tables lo (2^loglo) / hi (n >> loglo)
+  int logn, logn1, logn2;   // n = 2^logn1 x 2^logn2
   bool two_run;                    // two-pass sizes: 1024-point columns / rows as two 512-point runs (two workgroups per CU)
 };
 int big_split(int logn, BigGeom *g);
-// bigtabs: [half N1 | lo | hi]; sub: tables of the 2^logn2 row transform; scratch holds `batch`
+// bigtabs: [half N1 | W_n^k, k < 128 | W_n^(128 k), k < 128 | W_n^(16384 k), k < n / 16384]; sub: tables of the 2^logn2 row transform; scratch holds `batch`
 // transforms (batch <= 65535), scratch2 the row transform's own workspace (logn2 > kLdsMaxLog)
 // (out: where the last pass writes; data itself is only read)
 hipError_t launch_fft_big(const BigGeom &g, bool fwd, bool scale, cpx *data, cpx *out, cpx *scratch, cpx *scratch2,

@@ -652,7 +652,11 @@ def test_rfft_any_length(size, batch):
     assert_parity(c, want.astype(np.complex64), what="r2c size=%d" % size)
     r = np.zeros((batch, size), np.float32)
     assert i.transform(c, r) == 0
-    assert_parity(r, x, what="rfft round trip size=%d" % size)
+    # forward and inverse chained: two Bluestein transforms (four power-of-two transforms of the convolution length, eight chirp
+    # products).  Measured over sizes 96000 .. 786432 and three seeds: relL2 3.5-4.0e-7, worst sample 0.89-1.19e-6 (1.07e-6 in
+    # round 4's build as well, profiles/big_two_pass_r05.txt) — each direction alone is held to 1e-6 above, the pair to twice that,
+    # like the round trips of tests/fuzz_parity.py
+    assert_parity(r, x, tol=2e-6, what="rfft round trip size=%d" % size)
 
 
 def test_cfft_big_batch_chunks():
