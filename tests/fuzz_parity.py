@@ -1,7 +1,7 @@
 """Randomised parity sweep on the GPU box: `python tests/fuzz_parity.py [seconds] [seed]`, and — with a fixed seed and a
 bounded budget — a `-m gpu` test (tests/test_gpu_misc.py::test_randomised_parity_sweep calls run()).
 Random geometries of every object of the path — complex and packed real plans (powers of two with ragged batches, a
-few other lengths), partitioned convolutions (channels, partitions, static / time-varying, host and device entry
+few other lengths, the sizes above 65536), partitioned convolutions (channels, partitions, static / time-varying, host and device entry
 points), direct convolutions — each checked against the CPU oracle (numpy fp64 for the lengths the reference does not
 have).  Prints one line per case and a summary; exits non-zero on the first failure."""
 import os
@@ -63,6 +63,30 @@ def case_cfft():
     else:   # beyond the reference's range: numpy fp64 with the reference's scaling
         want = (np.fft.fft(x[pick].astype(np.complex128)) / n) if fwd else np.fft.ifft(x[pick].astype(np.complex128)) * n
     check("cfft", "n=2^%d batch=%d %s%s kernel=%s" % (logn, batch, "fwd" if fwd else "inv", " oop" if oop else "", p.kernel_name()), got[pick], want, 1e-6)
+
+
+def case_cfft_big():
+    """beyond the reference's range: two passes to 2^22 (three above), against numpy float64 under the reference's scaling"""
+    logn = int(rng.integers(17, 23))
+    n = 1 << logn
+    batch = int(rng.integers(1, max(2, min(6, (1 << 24) // n) + 1)))
+    fwd = bool(rng.integers(0, 2))
+    x = (sym((batch, n)) + 1j * sym((batch, n))).astype(np.complex64)
+    p = fa.Clcfft(0, n, fwd)
+    assert p.get_error() == 0, p.get_log()
+    d = torch.from_numpy(x.view(np.float32).reshape(batch, n, 2).copy()).cuda()
+    oop = bool(rng.integers(0, 3) == 0)
+    if oop:
+        dst = torch.full_like(d, float("nan"))
+        assert p.exec_device_oop(d, dst, batch) == 0
+        d = dst
+    else:
+        assert p.exec_device(d, batch) == 0
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().view(np.complex64).reshape(batch, n)
+    b = int(rng.integers(0, batch))
+    want = (np.fft.fft(x[b].astype(np.complex128)) / n) if fwd else np.fft.ifft(x[b].astype(np.complex128)) * n
+    check("big", "n=2^%d batch=%d %s%s kernel=%s" % (logn, batch, "fwd" if fwd else "inv", " oop" if oop else "", p.kernel_name()), got[b], want, 1e-6)
 
 
 def case_cfft_any():
@@ -176,7 +200,7 @@ def case_dconv():
     check("dconv", "irsize=%d vsize=%d %s %s blocks=%d" % (irsize, vsize, "tv" if tv else "static", "dev" if dev else "host", blocks), got, want, tol)
 
 
-cases = [case_cfft, case_cfft, case_rfft, case_rfft, case_pconv, case_pconv, case_pconv, case_dconv, case_dconv, case_cfft_any]
+cases = [case_cfft, case_cfft, case_rfft, case_rfft, case_pconv, case_pconv, case_pconv, case_dconv, case_dconv, case_cfft_any, case_cfft_big]
 
 
 def run(budget, seed, silent=False):
