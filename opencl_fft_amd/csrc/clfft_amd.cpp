@@ -664,7 +664,7 @@ size_t clfa_fft_workspace_bytes(const clfa_fft *p) {
 
 const char *clfa_fft_kernel_name(const clfa_fft *p) {
   if (!p) return "";
-  if (p->logn > kMaxLog) return "k_big_cols";
+  if (p->logn > kMaxLog) return p->big.logn2 <= 11 ? "k_big2_cols" : "k_big_cols";   // two passes (to 2^22) / three
   if (p->blue_m) return blue_lds_ok(p->blue_m) ? "k_blue_lds" : "bluestein";
   if (p->rlds15 || p->r2x13) return "k_rfft_2x";
   if (p->c2x13) return "k_cfft_2x";

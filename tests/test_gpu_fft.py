@@ -550,7 +550,7 @@ def test_streaming_batches_on_the_reduced_grid(real, n):
 # own to compare with: the yardstick is numpy's float64 FFT under the reference's conventions
 # (forward scaled by 1/n, inverse unscaled), same norm-relative 1e-6 criterion.
 
-@pytest.mark.parametrize("logn,batch", [(17, 3), (18, 2), (19, 1), (19, 2), (20, 2), (20, 1), (21, 1), (22, 1), (24, 1)])
+@pytest.mark.parametrize("logn,batch", [(17, 3), (18, 2), (19, 1), (19, 2), (20, 2), (20, 1), (21, 1), (21, 3), (22, 1), (22, 2), (23, 1), (24, 1)])
 def test_cfft_big_sizes(logn, batch):
     n = 1 << logn
     rng = np.random.default_rng(logn)
@@ -558,6 +558,7 @@ def test_cfft_big_sizes(logn, batch):
     f, i = fa.Clcfft(0, n, True), fa.Clcfft(0, n, False)
     assert f.get_error() == 0 and i.get_error() == 0
     assert f.workspace_bytes() >= 8 * n
+    assert f.kernel_name() == i.kernel_name() == ("k_big2_cols" if logn <= 22 else "k_big_cols")   # two passes / three
     y = x.copy()
     assert f.transform(y) == 0
     want = (np.fft.fft(x.astype(np.complex128), axis=-1) / n)
