@@ -26,7 +26,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                 r2c + c2r of size 131072 x 2048, the largest real size of the reference's range
   ms_per_step_cold / roofline.frac_cold   the same K steps after the same W warm-up steps taken FIRST, before
                 the full-size self-check (the chip is still inside its ~20 ms start-up clock ramp then);
-                config.effective_warmup_launches counts what ran before the headline's timed region
+                config.effective_warmup_launches counts what ran before the headline's timed region;
+                config.settle_launches of them are untimed steps worth --settle-ms (60) of device time right in front of
+                the W warm-up steps, so that the K timed steps read the chip's sustained clocks, not the tail of its ramp
 `--workload rfft | pconv` make one of the other configurations the headline of the line instead.
 """
 import argparse
@@ -55,6 +57,8 @@ def parse():
     ap.add_argument("--no-bandwidth", action="store_true", help="skip the device copy/read/write yardsticks")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the full-size property check before the warm-up")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold timed region taken before the self-check")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="device time of untimed steps in front of every workload's warm-up steps (0: none)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="headline workload only (profiling runs); default: N = 1 runs also time the other two configs")
     ap.add_argument("--series-out", default="", help="write the per-launch times (ms) of the timed region to this file")
@@ -271,6 +275,15 @@ class Workload:
             assert self.step(k) == 0
         self.launches_before_timed += count
 
+    def settle(self, ms):
+        """untimed steps worth `ms` of device time (counted at 5 TB/s of algorithmic traffic, an even number of them, the same
+        on every rank) right in front of a workload's W warm-up steps: the chip takes 20-60 ms of continuous work to reach its
+        sustained clocks (profiles/README.md, series_cold_start.txt), and the cold reading, the self-check's host round trips
+        and the construction of the next workload all leave it below them"""
+        count = 0 if ms <= 0 else (int(ms / (self.alg_bytes / 5e9)) + 2) & ~1
+        self.run(count)
+        return count
+
     def selfcheck(self):
         """Full-size guard BEFORE the headline is timed (a broken kernel must not get a number): on the benchmark's
         own buffer, at the benchmark's own size — the size-independent properties of the transform: round trip,
@@ -416,8 +429,9 @@ def main():
         chk = wl.selfcheck()
         if chk is not None:
             extra["full_size_selfcheck"] = chk
-    # 3. the headline: W warm-up steps, K timed steps — by now past the chip's start-up clock ramp
+    # 3. the headline: W warm-up steps, K timed steps — at the chip's sustained clocks (settle(): config.settle_launches)
     with torch.cuda.stream(stream):
+        extra["settle_launches"] = wl.settle(a.settle_ms)
         wl.run(W)
     extra["effective_warmup_launches"] = wl.launches_before_timed
     elapsed, avg_ms, per_launch_ms = wl.timed(K, barrier, series=bool(a.series_out))
@@ -477,10 +491,11 @@ def main():
                 o.run(w2)
             chk = None if a.no_selfcheck else o.selfcheck()
             with torch.cuda.stream(stream):
+                settled = o.settle(a.settle_ms)
                 o.run(w2)
             s2, ms2, _ = o.timed(k2, barrier)
             rec = {"workload": o.workload, "metric": o.metric, "value": o.units * k2 / s2 / 1e9, "unit": "Gsamples/s",
-                   "steps": k2, "warmup": w2, "effective_warmup_launches": o.launches_before_timed - k2,
+                   "steps": k2, "warmup": w2, "settle_launches": settled, "effective_warmup_launches": o.launches_before_timed - k2,
                    "ms_per_step": s2 / k2 * 1e3, "direction": o.direction, "roofline": o.roofline(ms2)}
             if chk is not None:
                 rec["full_size_selfcheck"] = chk

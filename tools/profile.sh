@@ -27,7 +27,7 @@ echo "== unprofiled"; cat "$OUT/bench_unprofiled.json"
 # cold start without the full-size guard (the chip's start-up clock ramp)
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bandwidth --no-other-workloads --series-out "$OUT/series_steps20.txt" $* > /dev/null 2>> "$OUT/bench_unprofiled.err"
 python3 bench.py $ARGS --series-out "$OUT/series_steps$STEPS.txt" > /dev/null 2>> "$OUT/bench_unprofiled.err"
-python3 bench.py --steps 60 --warmup 0 --no-cpu-baseline --no-bandwidth --no-other-workloads --no-selfcheck --series-out "$OUT/series_cold_start.txt" $* > /dev/null 2>> "$OUT/bench_unprofiled.err"
+python3 bench.py --steps 60 --warmup 0 --settle-ms 0 --no-cpu-baseline --no-bandwidth --no-other-workloads --no-selfcheck --series-out "$OUT/series_cold_start.txt" $* > /dev/null 2>> "$OUT/bench_unprofiled.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS > "$OUT/stats.log" 2>&1 || { tail -5 "$OUT/stats.log"; exit 2; }
 echo "== stats done"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
