@@ -123,6 +123,25 @@ def test_cfft_tiny_kernel_ragged(n, batch):
         assert torch.equal(dst.view(torch.int32), buf[:batch].view(torch.int32)), "out of place differs from in place"
 
 
+@pytest.mark.parametrize("n,batch", [(2, 3), (2, 100001), (4, 1), (4, 100001), (8, 1000), (16384, 5), (32768, 3)])
+def test_cfft_buffer_aligned_to_eight_bytes_only(n, batch):
+    """a complex buffer owes the library 8-byte alignment, not 16 (a view one sample into a larger buffer): the kernels that
+    move 16 bytes per lane (k_fft_tiny, the two-run kernels) must cope, and nothing outside the view may change"""
+    import torch
+    x = util.lcg_complex(n + batch, n * batch).reshape(batch, n)
+    big = torch.zeros((batch * n + 3, 2), device="cuda")
+    view = big[1:1 + batch * n].view(batch, n, 2)
+    assert view.data_ptr() % 16 == 8
+    view.copy_(torch.from_numpy(x.view(np.float32).reshape(batch, n, 2)))
+    plan = fa.Clcfft(0, n, True)
+    assert plan.exec_device(view, batch) == 0
+    torch.cuda.synchronize()
+    got = view.cpu().numpy().view(np.complex64).reshape(batch, n)
+    pick = sorted({0, batch // 2, batch - 1})
+    assert_parity(got[pick], oracle.cfft(x[pick], True), what="n=%d batch=%d (%s)" % (n, batch, plan.kernel_name()))
+    assert float(big[0].abs().sum()) == 0 and float(big[1 + batch * n:].abs().sum()) == 0
+
+
 def test_cfft_empty_batch_and_bad_sizes():
     plan = fa.Clcfft(0, 64, True)
     assert plan.transform(np.zeros((0, 64), np.complex64)) == 0
