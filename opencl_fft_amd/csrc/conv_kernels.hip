@@ -380,8 +380,7 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
   __syncthreads();
 
   // ---- forward chain(s): reference reorder + fft + r2c (cl_conv.cpp:399-419 / 465-513) ----------
-  auto forward = [&](const float *in, cpx *ring, int frame) {
-    cpx v[E];
+  auto forward_load = [&](const float *in, cpx (&v)[E]) {
     if (tid < T) {
       const cpx *src = reinterpret_cast<const cpx *>(in + (long)ch * N);
 #pragma unroll
@@ -390,6 +389,8 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
         v[e] = p < N / 2 ? src[p] : mk(0.f, 0.f);
       }
     }
+  };
+  auto forward_rest = [&](cpx (&v)[E], cpx *ring, int frame) {
     // all 256 lanes walk the barriers; lanes >= T carry dummies and touch no LDS slot of the transform
     if (tid < T) pass_compute<LOGB, G::LOGE, 0, true>(v, tid, s_tab);
     constexpr int LOGR0 = pass_logr(LOGB, G::LOGE, 0);
@@ -431,25 +432,48 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
       x[j] = oj;
     }
   };
-  forward(in1, ringA, frame1);
-  if constexpr (TV) forward(in2, ringB, frame2);
+  // Fewer channels than CUs (DEEP), static response: the MAC needs the frame stored below only for its LAST partition (the ring
+  // position frame1 = wp - 1 pairs with partition nparts - 1, clfa_pconv_process_dev), so the first kPre partitions are
+  // requested in front of the forward chain — behind the block's own samples: the counter of outstanding loads is in order —
+  // and land while it runs: a workgroup that is alone with its latency starts its MAC with a full queue (160 channels:
+  // 51.2-52.1 -> 46.0-46.5 us per block).  Same products, same order of the sums.  With a workgroup on every CU it buys
+  // nothing (256 channels 67.3-68.2 -> 68.7-69.5), profiles/pconv_prefetch_r05.txt.
+  constexpr int kPre = (TV || !DEEP || IPT > 2) ? 0 : 8;
+  const cpx2 *const mac_a = reinterpret_cast<const cpx2 *>(ringA + (long)ch * nparts * N);
+  const cpx2 *const mac_b = reinterpret_cast<const cpx2 *>(ringB + (long)ch * nparts * N);
+  [[maybe_unused]] cpx2 pa[kPre ? kPre : 1][IPT], pb[kPre ? kPre : 1][IPT];
+  [[maybe_unused]] const bool pre = kPre > 0 && nparts >= 4 * kPre;   // uniform (9 .. 12 partitions: +3 %, 40 and more: 0 .. -12 %)
+  cpx vin[E];
+  forward_load(in1, vin);
+  if constexpr (kPre > 0) {
+    if (pre) {
+#pragma unroll
+      for (int q = 0; q < kPre; q++) {
+        const int fq = wp + q < nparts ? wp + q : wp + q - nparts;
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+          pa[q][k] = ld_stream(mac_a + (long)fq * HB + tid + 256 * k);
+          pb[q][k] = ld_stream(mac_b + (long)q * HB + tid + 256 * k);
+        }
+      }
+    }
+  }
+  forward_rest(vin, ringA, frame1);
+  if constexpr (TV) {
+    forward_load(in2, vin);
+    forward_rest(vin, ringB, frame2);
+  }
   __syncthreads();   // the frames just stored are re-read below by this workgroup
 
   // ---- MAC over all partitions (reference convol, cl_conv_kernels.h:102-118) -----------------------
   {
-    const cpx2 *a = reinterpret_cast<const cpx2 *>(ringA + (long)ch * nparts * N);
-    const cpx2 *b = reinterpret_cast<const cpx2 *>(ringB + (long)ch * nparts * N);
+    const cpx2 *a = mac_a;
+    const cpx2 *b = mac_b;
     cpx s0[IPT], s1[IPT];
 #pragma unroll
     for (int k = 0; k < IPT; k++) s0[k] = s1[k] = mk(0.f, 0.f);
     int fr = wp;
-    auto step = [&](int p) {
-      cpx2 av[IPT], bv[IPT];
-#pragma unroll
-      for (int k = 0; k < IPT; k++) {
-        av[k] = ld_stream(a + (long)fr * HB + tid + 256 * k);
-        bv[k] = ld_stream(b + (long)p * HB + tid + 256 * k);
-      }
+    auto mac = [&](const cpx2 (&av)[IPT], const cpx2 (&bv)[IPT]) {
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
         cpx pr = cmul_plain(av[k].a, bv[k].a);
@@ -460,16 +484,34 @@ __global__ __launch_bounds__(256) void k_pconv_fused(const float *__restrict__ i
         s0[k] = cadd(s0[k], pr);
         s1[k] = cadd(s1[k], cmul_plain(av[k].b, bv[k].b));
       }
+    };
+    auto step = [&](int p) {
+      cpx2 av[IPT], bv[IPT];
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        av[k] = ld_stream(a + (long)fr * HB + tid + 256 * k);
+        bv[k] = ld_stream(b + (long)p * HB + tid + 256 * k);
+      }
+      mac(av, bv);
       fr = fr + 1 < nparts ? fr + 1 : 0;
     };
+    int p0 = 0;
+    if constexpr (kPre > 0) {
+      if (pre) {
+#pragma unroll
+        for (int q = 0; q < kPre; q++) mac(pa[q], pb[q]);
+        p0 = kPre;
+        fr = wp + kPre < nparts ? wp + kPre : wp + kPre - nparts;
+      }
+    }
     // loads of 4 partitions in flight per lane fill the memory system when every CU has a workgroup; with fewer
     // channels than CUs (DEEP) a workgroup is alone with its latency and 8 pay (160 channels: 55.5 -> 51.8 us)
     if constexpr (DEEP) {
 #pragma unroll 8
-      for (int p = 0; p < nparts; p++) step(p);
+      for (int p = p0; p < nparts; p++) step(p);
     } else {
 #pragma unroll 4
-      for (int p = 0; p < nparts; p++) step(p);
+      for (int p = p0; p < nparts; p++) step(p);
     }
 #pragma unroll
     for (int k = 0; k < IPT; k++) {

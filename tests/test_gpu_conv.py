@@ -359,7 +359,11 @@ def test_config4_full_size_properties():
 
 @pytest.mark.parametrize("pts,nparts,channels,blocks,tv", [(512, 5, 162, 7, False), (1024, 4, 160, 6, True),
                                                           (2048, 3, 170, 5, False), (4096, 2, 160, 4, True),
-                                                          (1024, 6, 260, 5, False)])
+                                                          (1024, 6, 260, 5, False),
+                                                          # fewer channels than CUs, static response, 32 partitions and more: the
+                                                          # first eight are requested in front of the forward chain (the ring wraps)
+                                                          (1024, 40, 160, 47, False), (512, 33, 200, 40, False),
+                                                          (1024, 32, 140, 5, False), (1024, 36, 170, 6, True)])
 def test_pconv_fused_block_kernel_vs_oracle(pts, nparts, channels, blocks, tv):
     """enough channels to select the one-launch-per-block kernel (forward + MAC + inverse per channel)"""
     s = util.lcg_half(21 + pts, channels * (pts * nparts + 2 * pts * blocks))
