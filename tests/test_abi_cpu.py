@@ -121,6 +121,33 @@ def test_handover_kernels_code_object_audit(tmp_path):
     assert not problems, "\n".join(problems[:10])
 
 
+def test_tiny_kernel_code_object_audit(tmp_path):
+    """fft_kernels.hip: k_fft_tiny<2> (n = 4) exchanges the halves of a transform between its two lanes through the DPP crossbar —
+    on the compiled ISA: quad_perm:[1,0,3,2] operands, 16-byte loads and stores, no LDS instruction, no scratch; and the
+    pass-to-pass twiddles of the column kernels above 65536 points come from LDS (no global table lookups: their only
+    vector-memory instructions are the 16 + 16 that move a lane's data ... 32 + 32 for the two-run forms)"""
+    import re
+    text = open(_compile_to_asm(tmp_path, "fft_kernels")).read()
+    bodies = {}
+    for m in re.finditer(r"^(_ZN4clfa\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M):
+        bodies[m.group(1)] = m.group(2)
+    tiny4 = [k for k in bodies if "10k_fft_tinyILi2E" in k]
+    assert len(tiny4) >= 3, sorted(bodies)[:5]
+    for k in tiny4:
+        b = bodies[k]
+        assert "quad_perm:[1,0,3,2]" in b, k
+        assert "global_load_dwordx4" in b and "global_store_dwordx4" in b, k
+        assert not re.search(r"\bds_\w+", b) and "scratch_" not in b, k
+    for k in [k for k in bodies if "10k_fft_tinyILi1E" in k]:
+        assert "dpp" not in bodies[k] and not re.search(r"\bds_\w+", bodies[k]), k
+    cols = [k for k in bodies if "14k_big2_cols_2x" in k or "11k_big2_colsI" in k]
+    assert len(cols) >= 6, len(cols)
+    for k in cols:
+        loads = len(re.findall(r"\b(global|buffer|flat)_load_\w+", bodies[k]))
+        per_lane = 32 if "cols_2x" in k else 16
+        assert loads <= per_lane + 12, (k, loads)   # data + the tables' copy into LDS at the start
+
+
 def test_resident_kernel_code_object_audit(tmp_path):
     """fft_resident.hip manages the accumulation registers and v[224:255] by hand; tools/check_isa.py
     verifies on the freshly compiled ISA that hipcc put nothing of its own there and uses no scratch"""
