@@ -538,7 +538,8 @@ def test_config3_full_size_roundtrip():
 
 
 @pytest.mark.parametrize("real,n", [(False, 8), (False, 16), (False, 32), (False, 64), (False, 128), (False, 256), (False, 512), (False, 1024),
-                                    (False, 2048), (False, 4096), (False, 8192), (True, 8), (True, 16), (True, 1024), (True, 2048), (True, 4096)])
+                                    (False, 2048), (False, 4096), (False, 8192), (True, 8), (True, 16), (True, 32), (True, 64), (True, 256), (True, 512),
+                                    (True, 1024), (True, 2048), (True, 4096), (True, 8192)])
 def test_streaming_batches_on_the_reduced_grid(real, n):
     """1 GiB of transforms per launch and one more (ragged): from there the persistent grids of k_fft_small / k_fft_lds put
     one or two workgroups on a CU instead of all that fit (wgs_per_cu(), fft_kernels.hip) — same transforms, longer
