@@ -877,8 +877,8 @@ __global__ __launch_bounds__(256) void k_fft_small(cpx *__restrict__ data, long 
 // interleaved A/Bs on random data, directions alternating (profiles/wgs_per_cu_r05.txt; one / two / three / all that fit):
 // n = 1024 at one workgroup per CU 6.02 TB/s, at the three that fit 5.37; n = 16 .. 2048 and 8192 -4 .. -11 % of the time;
 // n = 8 and n = 4096 like two.  The packed real kernels' pair maps stall between barriers, so most of them want company:
-// sizes 8, 16, 64 .. 512, 4096 take two, sizes 32, 1024, 2048 one, size 8192 one forward and two inverse (-2 .. -22 %
-// against what fits at 2 GiB per launch), size 16384 stays (every choice within 1 %).
+// sizes 8, 16, 64 .. 512, 2048, 4096 take two, sizes 32 and 1024 one (-2 .. -22 % against what fits at 2 GiB per launch),
+// sizes 8192 and 16384 stay.
 // (CLFA_WGS_TABLE 0: round 4's grids; CLFA_WGS_C / CLFA_WGS_RF + CLFA_WGS_RI: one figure for every size, for A/B builds.)
 // All of this holds for batches that STREAM from HBM: up to about twice the 256 MiB Infinity Cache the same A/B reads the
 // other way (n = 1024: 16 MiB +21 %, 256 MiB +2 %, 512 MiB -5 %, 1 GiB -10 %; n = 64 still +8 % at 768 MiB, -4 % at 1 GiB),
@@ -899,10 +899,11 @@ template <int LOGN, int MODE> constexpr int wgs_per_cu() {
   return MODE == MODE_R2C ? CLFA_WGS_RF : CLFA_WGS_RI;
 #endif
   switch (LOGN) {   // packed real size 2^(LOGN + 1), at 2 GiB per launch (the second table of profiles/wgs_per_cu_r05.txt)
-    case 4: case 9: case 10: return 1;
-    case 2: case 3: case 5: case 6: case 7: case 8: case 11: return 2;
-    case 12: return MODE == MODE_R2C ? 1 : 2;
-    default: return 64;   // (size 16384: one or two, forward or inverse, within 1 %)
+    // (size 16384: one or two, forward or inverse, within 1 %; size 8192: -2 % at best; size 2048 with one: -7 % at 2 GiB,
+    // but behind two in a sweep at 1 GiB — two is never behind)
+    case 4: case 9: return 1;
+    case 2: case 3: case 5: case 6: case 7: case 8: case 10: case 11: return 2;
+    default: return 64;
   }
 }
 
