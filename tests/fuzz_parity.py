@@ -167,6 +167,36 @@ def case_pconv():
           got, want, max(1e-6, 1e-7 * float(np.sqrt(nparts))))   # float32 sums of nparts products in two orders: 3.5e-7 at 94 partitions (profiles/conv_accuracy_r05.txt)
 
 
+def case_pconv_deep():
+    """k_pconv_fused with fewer channels than CUs and 32 partitions or more (static response): the first eight partitions are
+    requested in front of the forward chain; a few channels against the oracle, the ring wrapping when there are enough blocks"""
+    pts = int(rng.choice([512, 1024]))
+    nparts = int(rng.integers(32, 49))
+    channels = int(rng.integers(137, 256))
+    blocks = int(rng.choice([3, 5, nparts + 3]))
+    cvs = pts * nparts
+    p = fa.Clpconv(0, cvs, pts, channels=channels)
+    assert p.get_cl_err() == 0 and p.nparts == nparts
+    ir = (sym((channels, cvs)) * (0.5 / np.sqrt(cvs))).astype(np.float32)
+    assert p.push_ir(ir) == 0
+    x1 = sym((blocks, channels, pts))
+    d1 = torch.from_numpy(x1).cuda()
+    dout = torch.zeros((blocks, channels, pts), device="cuda")
+    for b in range(blocks):
+        assert p.process_device(dout[b], d1[b], None) == 0
+    torch.cuda.synchronize()
+    got = dout.cpu().numpy()
+    pick = sorted({0, channels - 1, int(rng.integers(0, channels)), int(rng.integers(0, channels))})
+    want = np.zeros((blocks, len(pick), pts), np.float32)
+    for k, c in enumerate(pick):
+        o = oracle.Pconv(cvs, pts)
+        o.push_ir(ir[c])
+        for b in range(blocks):
+            want[b, k] = o.convolution(x1[b, c])
+    check("pconv", "pts=%d parts=%d ch=%d static dev blocks=%d kernel=%s (deep queue)" % (pts, nparts, channels, blocks, p.kernel_name()),
+          got[:, pick], want, max(1e-6, 1e-7 * float(np.sqrt(nparts))))
+
+
 def case_dconv():
     irsize = int(rng.choice([int(rng.integers(1, 64)), int(rng.integers(64, 5000)), int(rng.integers(5000, 200000))]))
     vsize = int(rng.choice([int(rng.integers(1, 130)), int(rng.integers(130, 3000))]))
@@ -200,7 +230,8 @@ def case_dconv():
     check("dconv", "irsize=%d vsize=%d %s %s blocks=%d" % (irsize, vsize, "tv" if tv else "static", "dev" if dev else "host", blocks), got, want, tol)
 
 
-cases = [case_cfft, case_cfft, case_rfft, case_rfft, case_pconv, case_pconv, case_pconv, case_dconv, case_dconv, case_cfft_any, case_cfft_big]
+cases = [case_cfft, case_cfft, case_rfft, case_rfft, case_pconv, case_pconv, case_pconv, case_dconv, case_dconv, case_cfft_any, case_cfft_big,
+         case_pconv_deep]
 
 
 def run(budget, seed, silent=False):
